@@ -1,0 +1,325 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes loader for oracle/liboracle.so (the CPU restatement).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Parity status: "parity unpinned" (see oracle/field.hpp).
+
+Conventions: field elements are numpy uint64[4] (Montgomery form, little-endian limbs), points are
+uint64[8] (x || y, identity = all zero); vectors are C-contiguous arrays of those.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SECQ, ZORRO = 0, 1
+SC_SHUFFLE, SC_RANGE, SC_EXAMPLE, SC_SQUARE_CHAIN, SC_MULTI_RANGE = 0, 1, 2, 3, 4
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_msm_timed.restype = C.c_double
+        _LIB.orc_transcript_new.restype = C.c_void_p
+        _LIB.orc_transcript_clone.restype = C.c_void_p
+        _LIB.orc_init()
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(n):
+    return np.zeros(n, dtype=np.uint64)
+
+
+def fid(curve, scalar_field):
+    return 2 * curve + (1 if scalar_field else 0)
+
+
+# ---- fields -------------------------------------------------------------------------------
+def modulus(f):
+    o = _u64(4)
+    lib().orc_fe_modulus(f, _p(o))
+    return limbs_to_int(o)
+
+
+def limbs_to_int(a):
+    return sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(a, dtype=np.uint64).reshape(-1)[:4]))
+
+
+def int_to_limbs(x):
+    return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def fe_from_int(f, x):
+    o = _u64(4)
+    lib().orc_fe_from_canon(f, _p(int_to_limbs(x % modulus(f))), _p(o))
+    return o
+
+
+def fe_to_int(f, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    o = _u64(4)
+    lib().orc_fe_to_canon(f, _p(a), _p(o))
+    return limbs_to_int(o)
+
+
+def fe_op(name, f, a, b=None):
+    o = _u64(4)
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    fn = getattr(lib(), "orc_fe_" + name)
+    if b is None:
+        rc = fn(f, _p(a), _p(o))
+        return o if rc == 0 else None
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    fn(f, _p(a), _p(b), _p(o))
+    return o
+
+
+def fe_rand(f, seed, count):
+    o = _u64(4 * count)
+    lib().orc_fe_rand(f, bytes(seed), C.c_size_t(count), _p(o))
+    return o.reshape(count, 4)
+
+
+# ---- bytes --------------------------------------------------------------------------------
+def sha3_512(msg):
+    out = C.create_string_buffer(64)
+    lib().orc_sha3_512(bytes(msg), C.c_size_t(len(msg)), out)
+    return out.raw
+
+
+def chacha20_words(seed, n):
+    o = np.zeros(n, dtype=np.uint32)
+    lib().orc_chacha20_words(bytes(seed), C.c_size_t(n), _p(o))
+    return o
+
+
+class Transcript:
+    def __init__(self, label=None, handle=None):
+        self.h = C.c_void_p(handle if handle is not None else lib().orc_transcript_new(bytes(label), C.c_size_t(len(label))))
+
+    def clone(self):
+        return Transcript(handle=lib().orc_transcript_clone(self.h))
+
+    def __del__(self):
+        try:
+            lib().orc_transcript_free(self.h)
+        except Exception:
+            pass
+
+    def append_message(self, label, msg):
+        lib().orc_transcript_append_message(self.h, bytes(label), bytes(msg), C.c_size_t(len(msg)))
+
+    def append_u64(self, label, x):
+        lib().orc_transcript_append_u64(self.h, bytes(label), C.c_uint64(x))
+
+    def challenge_bytes(self, label, n):
+        out = C.create_string_buffer(n)
+        lib().orc_transcript_challenge_bytes(self.h, bytes(label), out, C.c_size_t(n))
+        return out.raw
+
+    def append_point(self, curve, label, xy):
+        lib().orc_transcript_append_point(curve, self.h, bytes(label), _p(np.ascontiguousarray(xy, dtype=np.uint64)))
+
+    def append_scalar(self, curve, label, s):
+        lib().orc_transcript_append_scalar(curve, self.h, bytes(label), _p(np.ascontiguousarray(s, dtype=np.uint64)))
+
+    def challenge_scalar(self, curve, label):
+        o = _u64(4)
+        lib().orc_transcript_challenge_scalar(curve, self.h, bytes(label), _p(o))
+        return o
+
+    def rng_draws(self, curve, witness, seed, count):
+        w = np.ascontiguousarray(witness, dtype=np.uint64).reshape(-1, 4)
+        o = _u64(4 * count)
+        lib().orc_transcript_rng_draws(curve, self.h, _p(w), C.c_size_t(len(w)), bytes(seed), C.c_size_t(count), _p(o))
+        return o.reshape(count, 4)
+
+
+# ---- group --------------------------------------------------------------------------------
+def generator(curve):
+    o = _u64(8)
+    lib().orc_generator(curve, _p(o))
+    return o
+
+
+def on_curve(curve, xy):
+    return bool(lib().orc_on_curve(curve, _p(np.ascontiguousarray(xy, dtype=np.uint64))))
+
+
+def point_add(curve, p, q):
+    o = _u64(8)
+    lib().orc_point_add(curve, _p(np.ascontiguousarray(p, dtype=np.uint64)), _p(np.ascontiguousarray(q, dtype=np.uint64)), _p(o))
+    return o
+
+
+def scalar_mul(curve, p, s):
+    o = _u64(8)
+    lib().orc_scalar_mul(curve, _p(np.ascontiguousarray(p, dtype=np.uint64)), _p(np.ascontiguousarray(s, dtype=np.uint64)), _p(o))
+    return o
+
+
+def point_ser(curve, p, compressed):
+    out = C.create_string_buffer(33 if compressed else 65)
+    lib().orc_point_ser(curve, _p(np.ascontiguousarray(p, dtype=np.uint64)), int(compressed), out)
+    return out.raw
+
+
+def point_deser_compressed(curve, b):
+    o = _u64(8)
+    rc = lib().orc_point_deser_compressed(curve, bytes(b), _p(o))
+    return o if rc == 0 else None
+
+
+def msm(curve, bases, scalars, timed=False):
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    assert len(bases) == len(scalars)
+    o = _u64(8)
+    if timed:
+        t = lib().orc_msm_timed(curve, _p(bases), _p(scalars), C.c_size_t(len(bases)), _p(o))
+        return o, t
+    lib().orc_msm(curve, _p(bases), _p(scalars), C.c_size_t(len(bases)), _p(o))
+    return o
+
+
+def pedersen_default(curve):
+    b, bb = _u64(8), _u64(8)
+    lib().orc_pedersen_default(curve, _p(b), _p(bb))
+    return b, bb
+
+
+def pedersen_commit(curve, v, blind):
+    o = _u64(8)
+    lib().orc_pedersen_commit(curve, _p(np.ascontiguousarray(v, dtype=np.uint64)), _p(np.ascontiguousarray(blind, dtype=np.uint64)), _p(o))
+    return o
+
+
+def bp_gens(curve, cap):
+    g, h = _u64(8 * cap), _u64(8 * cap)
+    lib().orc_bp_gens(curve, C.c_size_t(cap), _p(g), _p(h))
+    return g.reshape(cap, 8), h.reshape(cap, 8)
+
+
+def bp_gens_party(curve, cap, party):
+    g, h = _u64(8 * cap), _u64(8 * cap)
+    lib().orc_bp_gens_party(curve, C.c_size_t(cap), C.c_size_t(party), _p(g), _p(h))
+    return g.reshape(cap, 8), h.reshape(cap, 8)
+
+
+# ---- IPA ---------------------------------------------------------------------------------
+def ipa_create(curve, tr, Q, Gf, Hf, G, H, a, b):
+    n = len(G)
+    lg = max(n.bit_length() - 1, 0)
+    L, R, ao, bo = _u64(8 * max(lg, 1)), _u64(8 * max(lg, 1)), _u64(4), _u64(4)
+    arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in (Q, Gf, Hf, G, H, a, b)]
+    k = lib().orc_ipa_create(curve, tr.h, *[_p(x) for x in arrs], C.c_size_t(n), _p(L), _p(R), _p(ao), _p(bo))
+    return L.reshape(-1, 8)[:k], R.reshape(-1, 8)[:k], ao, bo
+
+
+def ipa_verify(curve, tr, n, Gf, Hf, P, Q, G, H, L, R, a, b):
+    arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in (Gf, Hf, P, Q, G, H, L, R)]
+    lgn = len(np.asarray(L).reshape(-1, 8)) if np.asarray(L).size else 0
+    return lib().orc_ipa_verify(curve, tr.h, C.c_size_t(n), *[_p(x) for x in arrs], C.c_size_t(lgn),
+                                _p(np.ascontiguousarray(a, dtype=np.uint64)), _p(np.ascontiguousarray(b, dtype=np.uint64)))
+
+
+def ipa_verification_scalars(curve, tr, n, L, R):
+    L = np.ascontiguousarray(L, dtype=np.uint64).reshape(-1, 8)
+    R = np.ascontiguousarray(R, dtype=np.uint64).reshape(-1, 8)
+    lgn = len(L)
+    us, uis, s = _u64(4 * max(lgn, 1)), _u64(4 * max(lgn, 1)), _u64(4 * n)
+    rc = lib().orc_ipa_verification_scalars(curve, tr.h, C.c_size_t(n), _p(L), _p(R), C.c_size_t(lgn), _p(us), _p(uis), _p(s))
+    if rc:
+        return None
+    return us.reshape(-1, 4)[:lgn], uis.reshape(-1, 4)[:lgn], s.reshape(n, 4)
+
+
+# ---- R1CS scenarios ------------------------------------------------------------------------
+def _params(params):
+    a = np.zeros(8, dtype=np.uint64)
+    a[: len(params)] = np.array(params, dtype=np.uint64)
+    return a
+
+
+class Proved:
+    def __init__(self, rc, proof=b"", commitments=None, publics=None, t_prove=0.0, t_setup=0.0):
+        self.rc, self.proof, self.commitments, self.publics = rc, proof, commitments, publics
+        self.t_prove, self.t_setup = t_prove, t_setup
+
+
+def r1cs_prove(curve, scenario, params, seed, gens_cap, m_cap=None):
+    prm = _params(params)
+    if m_cap is None:
+        m_cap = 2 * int(prm[0]) + 8
+    buf = C.create_string_buffer(1 << 16)
+    plen = C.c_size_t(len(buf))
+    commits = _u64(8 * m_cap)
+    m = C.c_size_t(0)
+    pubs = _u64(4 * 8)
+    npub = C.c_size_t(0)
+    timing = (C.c_double * 2)()
+    rc = lib().orc_r1cs_prove(curve, scenario, _p(prm), bytes(seed), C.c_size_t(gens_cap), buf, C.byref(plen), _p(commits), C.c_size_t(m_cap),
+                              C.byref(m), _p(pubs), C.byref(npub), timing)
+    if rc:
+        return Proved(rc)
+    return Proved(0, buf.raw[: plen.value], commits.reshape(-1, 8)[: m.value].copy(), pubs.reshape(-1, 4)[: npub.value].copy(), timing[0], timing[1])
+
+
+def r1cs_verify(curve, scenario, params, gens_cap, proof, commitments, publics, timing=None):
+    prm = _params(params)
+    cm = np.ascontiguousarray(commitments, dtype=np.uint64).reshape(-1, 8)
+    pb = np.ascontiguousarray(publics, dtype=np.uint64).reshape(-1, 4)
+    t = (C.c_double * 1)()
+    rc = lib().orc_r1cs_verify(curve, scenario, _p(prm), C.c_size_t(gens_cap), bytes(proof), C.c_size_t(len(proof)), _p(cm), C.c_size_t(len(cm)),
+                               _p(pb), C.c_size_t(len(pb)), t)
+    if timing is not None:
+        timing.append(t[0])
+    return rc
+
+
+def r1cs_verification_scalars(curve, scenario, params, gens_cap, proof, commitments, publics, cap):
+    prm = _params(params)
+    cm = np.ascontiguousarray(commitments, dtype=np.uint64).reshape(-1, 8)
+    pb = np.ascontiguousarray(publics, dtype=np.uint64).reshape(-1, 4)
+    out = _u64(4 * cap)
+    cnt = C.c_size_t(0)
+    rc = lib().orc_r1cs_verification_scalars(curve, scenario, _p(prm), C.c_size_t(gens_cap), bytes(proof), C.c_size_t(len(proof)), _p(cm),
+                                             C.c_size_t(len(cm)), _p(pb), C.c_size_t(len(pb)), _p(out), C.c_size_t(cap), C.byref(cnt))
+    if rc:
+        return rc, None
+    return 0, out.reshape(-1, 4)[: cnt.value].copy()
+
+
+def batch_verify(curve, instances, gens_cap, alpha_seed, timing=None):
+    """instances: list of (scenario, params, proof_bytes, commitments, publics)"""
+    n = len(instances)
+    scen = (C.c_int * n)(*[i[0] for i in instances])
+    prm = np.concatenate([_params(i[1]) for i in instances])
+    proofs = b"".join(i[2] for i in instances)
+    plens = (C.c_size_t * n)(*[len(i[2]) for i in instances])
+    cms = np.ascontiguousarray(np.concatenate([np.asarray(i[3], dtype=np.uint64).reshape(-1, 8) for i in instances]))
+    ms = (C.c_size_t * n)(*[len(np.asarray(i[3]).reshape(-1, 8)) for i in instances])
+    pubs_l = [np.asarray(i[4], dtype=np.uint64).reshape(-1, 4) for i in instances]
+    pubs = np.ascontiguousarray(np.concatenate(pubs_l + [np.zeros((1, 4), dtype=np.uint64)]))
+    npubs = (C.c_size_t * n)(*[len(p) for p in pubs_l])
+    t = (C.c_double * 1)()
+    rc = lib().orc_batch_verify(curve, C.c_size_t(n), scen, _p(prm), C.c_size_t(gens_cap), proofs, plens, _p(cms), ms, _p(pubs), npubs,
+                                bytes(alpha_seed), t)
+    if timing is not None:
+        timing.append(t[0])
+    return rc
