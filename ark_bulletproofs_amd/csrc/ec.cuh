@@ -1,0 +1,199 @@
+// Short-Weierstrass group arithmetic for gfx950 on top of fp29.cuh (Jacobian X:Y:Z, a = 0 for
+// secq256k1, a = 6 for zorro — /root/reference/src/curve/zorro/g1.rs:24-38).  These are the group
+// operations behind every `G::Group::msm(..)` / `into_affine()` call site of the reference
+// (src/inner_product_proof.rs:104,124,143-155,187,202,219-224; src/r1cs/prover.rs:516-649;
+// src/r1cs/verifier.rs:574,685).  Results are group elements: after `into_affine` they are
+// bit-identical to ark-ec's whatever formulas either side uses.
+//
+// Invariants: coordinates of a stored Jac are L = 1, V <= 2 (see fp29.cuh); the identity has Z == 0
+// exactly.  Aff coordinates are canonical (V < 1); the identity is x = y = 0 (not on either curve).
+// All exceptional cases are handled (P+P, P+(-P), identity operands): batch verification legitimately
+// feeds identity points and duplicate bases (src/r1cs/verifier.rs:672-674).
+#pragma once
+#include "fp29.cuh"
+
+namespace arkbp {
+
+struct Aff {
+    Fe x, y;
+};
+struct Jac {
+    Fe X, Y, Z;
+};
+
+ARKBP_HD bool aff_is_inf(const Aff& p) { return fe_is_zero_exact(p.x) && fe_is_zero_exact(p.y); }
+ARKBP_HD bool jac_is_inf(const Jac& p) { return fe_is_zero_exact(p.Z); }
+template <class C> ARKBP_HD Jac jac_inf() {
+    Jac r;
+    r.X = fe_one<typename C::Fq>();
+    r.Y = fe_one<typename C::Fq>();
+    r.Z = fe_zero<typename C::Fq>();
+    return r;
+}
+template <class C> ARKBP_HD Jac jac_from_aff(const Aff& p) {
+    if (aff_is_inf(p)) return jac_inf<C>();
+    Jac r;
+    r.X = p.x;
+    r.Y = p.y;
+    r.Z = fe_one<typename C::Fq>();
+    return r;
+}
+template <class C> ARKBP_HD Aff aff_neg(const Aff& p) {
+    typedef typename C::Fq F;
+    Aff r;
+    r.x = p.x;
+    r.y = aff_is_inf(p) ? p.y : fe_canon<F>(fe_neg<F, 2>(p.y));
+    return r;
+}
+// conditional negation without the canonicalisation (fine as an operand of jac_madd: V(y) <= 3)
+template <class C> ARKBP_HD Aff aff_cneg_lazy(const Aff& p, bool neg) {
+    typedef typename C::Fq F;
+    Aff r;
+    r.x = p.x;
+    Fe ny = fe_neg<F, 2>(p.y);
+    const bool flip = neg && !aff_is_inf(p);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.y.l[i] = flip ? ny.l[i] : p.y.l[i];
+    return r;
+}
+
+// k*a for a small k, carried back to L = 1
+template <int K> ARKBP_HD Fe fe_times(const Fe& a) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] * (u32)K;  // K <= 8: no 32-bit overflow for L = 1
+    return fe_norm(r);
+}
+
+template <class C> ARKBP_HD Jac jac_dbl(const Jac& p) {
+    typedef typename C::Fq F;
+    if (jac_is_inf(p)) return p;
+    Jac o;
+    if (C::A_ZERO) {
+        // dbl-2009-l shape: A = X^2, B = Y^2, C = B^2, D = 4XB, E = 3A, X3 = E^2 - 2D, Y3 = E(D - X3) - 8C, Z3 = 2YZ
+        Fe A = fe_sqr<F>(p.X), B = fe_sqr<F>(p.Y), Cc = fe_sqr<F>(B);
+        Fe D = fe_times<4>(fe_mul<F>(p.X, B));             // V <= 4.3
+        Fe E = fe_times<3>(A);                             // V <= 3.4
+        Fe X3 = fe_wred<F>(fe_sub<F, 16>(fe_sqr<F>(E), fe_dbl(D)));
+        Fe Y3 = fe_mul<F>(E, fe_sub<F, 4>(D, X3));         // V(D - X3) <= 8.3
+        o.X = X3;
+        o.Y = fe_wred<F>(fe_sub<F, 16>(Y3, fe_times<8>(Cc)));
+        o.Z = fe_mul<F>(fe_dbl(p.Y), p.Z);
+    } else {
+        // dbl-2007-bl shape with M = 3XX + a*ZZ^2, S = 4*X*YY
+        Fe XX = fe_sqr<F>(p.X), YY = fe_sqr<F>(p.Y), YYYY = fe_sqr<F>(YY), ZZ = fe_sqr<F>(p.Z);
+        Fe S = fe_times<4>(fe_mul<F>(p.X, YY));
+        Fe Z4 = fe_sqr<F>(ZZ);
+        static_assert(C::A_ZERO || (C::A_SMALL >= 1 && C::A_SMALL <= 8), "curve coefficient a must be a small integer");
+        Fe aZ4 = fe_times<(C::A_ZERO ? 1 : C::A_SMALL)>(Z4);
+        Fe M = fe_norm(fe_add(fe_times<3>(XX), aZ4));      // V <= 3.4 + 6.3
+        Fe X3 = fe_wred<F>(fe_sub<F, 16>(fe_sqr<F>(M), fe_dbl(S)));
+        Fe Y3 = fe_mul<F>(M, fe_sub<F, 4>(S, X3));
+        o.X = X3;
+        o.Y = fe_wred<F>(fe_sub<F, 16>(Y3, fe_times<8>(YYYY)));
+        o.Z = fe_mul<F>(fe_dbl(p.Y), p.Z);
+    }
+    return o;
+}
+
+// Jacobian + affine.  q.y may be a lazy negation (V <= 3, L = 1).
+template <class C> ARKBP_HD Jac jac_madd(const Jac& p, const Aff& q) {
+    typedef typename C::Fq F;
+    if (aff_is_inf(q)) return p;
+    if (jac_is_inf(p)) {
+        Jac r;
+        r.X = q.x;
+        r.Y = fe_wred<F>(q.y);
+        r.Z = fe_one<F>();
+        return r;
+    }
+    Fe Z1Z1 = fe_sqr<F>(p.Z);
+    Fe U2 = fe_mul<F>(q.x, Z1Z1);
+    Fe S2 = fe_mul<F>(q.y, fe_mul<F>(p.Z, Z1Z1));
+    Fe H = fe_sub<F, 4>(U2, p.X);   // V <= 5.1
+    Fe r = fe_sub<F, 4>(S2, p.Y);
+    if (fe_is_zero_mod<F>(H)) {     // same x: doubling or cancellation (rare, duplicates only)
+        if (fe_is_zero_mod<F>(r)) return jac_dbl<C>(p);
+        return jac_inf<C>();
+    }
+    Fe HH = fe_sqr<F>(H);           // <= 1.8
+    Fe HHH = fe_mul<F>(H, HH);      // <= 1.3
+    Fe V = fe_mul<F>(p.X, HH);      // <= 1.2
+    Jac o;
+    o.X = fe_wred<F>(fe_sub<F, 4>(fe_sqr<F>(r), fe_add(HHH, fe_dbl(V))));
+    Fe Y3 = fe_mul<F>(r, fe_sub<F, 4>(V, o.X));
+    o.Y = fe_wred<F>(fe_sub<F, 2>(Y3, fe_mul<F>(p.Y, HHH)));
+    o.Z = fe_mul<F>(p.Z, H);
+    return o;
+}
+
+// Jacobian + Jacobian
+template <class C> ARKBP_HD Jac jac_add(const Jac& p, const Jac& q) {
+    typedef typename C::Fq F;
+    if (jac_is_inf(q)) return p;
+    if (jac_is_inf(p)) return q;
+    Fe Z1Z1 = fe_sqr<F>(p.Z), Z2Z2 = fe_sqr<F>(q.Z);
+    Fe U1 = fe_mul<F>(p.X, Z2Z2), U2 = fe_mul<F>(q.X, Z1Z1);
+    Fe S1 = fe_mul<F>(p.Y, fe_mul<F>(q.Z, Z2Z2)), S2 = fe_mul<F>(q.Y, fe_mul<F>(p.Z, Z1Z1));
+    Fe H = fe_sub<F, 2>(U2, U1);    // V <= 3.2
+    Fe r = fe_sub<F, 2>(S2, S1);
+    if (fe_is_zero_mod<F>(H)) {
+        if (fe_is_zero_mod<F>(r)) return jac_dbl<C>(p);
+        return jac_inf<C>();
+    }
+    Fe HH = fe_sqr<F>(H);
+    Fe HHH = fe_mul<F>(H, HH);
+    Fe V = fe_mul<F>(U1, HH);
+    Jac o;
+    o.X = fe_wred<F>(fe_sub<F, 4>(fe_sqr<F>(r), fe_add(HHH, fe_dbl(V))));
+    Fe Y3 = fe_mul<F>(r, fe_sub<F, 4>(V, o.X));
+    o.Y = fe_wred<F>(fe_sub<F, 2>(Y3, fe_mul<F>(S1, HHH)));
+    o.Z = fe_mul<F>(fe_mul<F>(p.Z, q.Z), H);
+    return o;
+}
+
+// (X/Z^2, Y/Z^3) given zinv = 1/Z; canonical output
+template <class C> ARKBP_HD Aff jac_to_aff_with_zinv(const Jac& p, const Fe& zinv) {
+    typedef typename C::Fq F;
+    Aff r;
+    if (jac_is_inf(p)) {
+        r.x = fe_zero<F>();
+        r.y = fe_zero<F>();
+        return r;
+    }
+    Fe zi2 = fe_sqr<F>(zinv);
+    r.x = fe_canon<F>(fe_mul<F>(p.X, zi2));
+    r.y = fe_canon<F>(fe_mul<F>(p.Y, fe_mul<F>(zi2, zinv)));
+    return r;
+}
+template <class C> ARKBP_HD Aff jac_to_aff(const Jac& p) {
+    return jac_to_aff_with_zinv<C>(p, fe_inv<typename C::Fq>(p.Z));
+}
+
+// ---- 64-byte affine points in memory ------------------------------------------------------------
+// ark layout at the C ABI: x || y as 8+8 u32 words, Montgomery w.r.t. 2^256; identity = all zero.
+template <class C> ARKBP_HD Aff aff_load_ark(const u32* w) {
+    typedef typename C::Fq F;
+    Aff r;
+    r.x = fe_canon<F>(fe_load_ark<F>(w));
+    r.y = fe_canon<F>(fe_load_ark<F>(w + 8));
+    return r;  // all-zero words -> exact zero limbs -> identity
+}
+template <class C> ARKBP_HD void aff_store_ark(u32* w, const Aff& p) {
+    typedef typename C::Fq F;
+    fe_store_ark<F>(w, p.x);
+    fe_store_ark<F>(w + 8, p.y);
+}
+// device-resident layout: packed R' form
+ARKBP_HD Aff aff_load_dev(const u32* w) {
+    Aff r;
+    r.x = fe_unpack(w);
+    r.y = fe_unpack(w + 8);
+    return r;
+}
+ARKBP_HD void aff_store_dev(u32* w, const Aff& p) {  // p canonical
+    fe_pack(w, p.x);
+    fe_pack(w + 8, p.y);
+}
+
+}  // namespace arkbp

@@ -1,0 +1,293 @@
+// 256-bit prime-field arithmetic for gfx950 (CDNA4) in a reduced radix: 9 limbs of 29 bits.
+//
+// Why this shape (measured on MI355X, tools/ubench.hip, profiles/r01_ubench.txt): v_mad_u64_u32
+// issues at the same half rate as v_mul_lo_u32 / v_mad_u32_u24, so it is the widest multiplier per
+// issue slot; what makes a 32-bit-limb Montgomery product slow is carry plumbing (≈4.5 VALU per limb
+// product).  With 29-bit limbs a column of 18 products fits a 64-bit accumulator, so a product is ONE
+// v_mad_u64_u32 and carries are extracted once per column; additions need no carry chain at all.
+//
+// Representation: x stands for the residue x * R'^-1 mod p with R' = 2^261 (Montgomery form w.r.t.
+// R').  Buffers that cross the C ABI use ark-ff's layout (4 x u64, Montgomery w.r.t. R = 2^256 — what
+// the reference's Fp256<MontBackend<_,4>> holds at e.g. src/inner_product_proof.rs:140-141);
+// `fe_load_ark` / `fe_store_ark` convert at the boundary with one Montgomery product each.
+// Device-resident tables keep the R' form, packed into 32 bytes (value < p).
+//
+// Contracts (checked on the CPU by tests/test_fp29_host.py through csrc/fp29_selftest.cpp when
+// ARKBP_CHECK_BOUNDS is defined).  L = largest limb / 2^29, V = value / p:
+//   fe_mul / fe_sqr   in: L(a)*L(b) <= 6, V(a)*V(b) <= 900   out: L = 1, V < V(a)V(b)/32 + 1
+//   fe_add            limb-wise, no carry                    out: L = La + Lb, V = Va + Vb
+//   fe_sub<K>         in: L(a) <= 2, L(b) < 4, V(b) < K      out: L = 1, V = Va + K
+//   fe_norm           carry pass                              out: L = 1
+//   fe_wred           in: L = 1, V < 32                       out: L = 1, V <= 2
+//   fe_canon          in: L = 1, V < 32                       out: canonical (0 <= x < p)
+#pragma once
+#include <cstdint>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ARKBP_HD __host__ __device__ __forceinline__
+#else
+#define ARKBP_HD inline
+#endif
+#include "arkbp_params.h"
+
+#ifdef ARKBP_CHECK_BOUNDS
+#include <cstdio>
+#include <cstdlib>
+#define ARKBP_ASSERT(c, msg) do { if (!(c)) { fprintf(stderr, "fp29 bound violated: %s (%s:%d)\n", msg, __FILE__, __LINE__); abort(); } } while (0)
+#else
+#define ARKBP_ASSERT(c, msg)
+#endif
+
+namespace arkbp {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+static constexpr u32 M29 = (1u << 29) - 1;
+
+struct Fe {
+    u32 l[9];
+};
+
+template <class P> ARKBP_HD Fe fe_zero() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = 0;
+    return r;
+}
+template <class P> ARKBP_HD Fe fe_one() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = P::ONE29[i];
+    return r;
+}
+template <class P, const u32 (&C)[9]> ARKBP_HD Fe fe_const() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = C[i];
+    return r;
+}
+// exact all-limbs-zero test (the identity's Z is stored as exact zero)
+ARKBP_HD bool fe_is_zero_exact(const Fe& a) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.l[i];
+    return o == 0;
+}
+ARKBP_HD bool fe_eq_exact(const Fe& a, const Fe& b) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.l[i] ^ b.l[i];
+    return o == 0;
+}
+
+// carry pass: limbs 0..7 < 2^29 afterwards; limb 8 keeps the excess
+ARKBP_HD Fe fe_norm(const Fe& a) {
+    Fe r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 t = a.l[i] + c;
+        r.l[i] = t & M29;
+        c = t >> 29;
+    }
+    r.l[8] = a.l[8] + c;
+    return r;
+}
+
+ARKBP_HD Fe fe_add(const Fe& a, const Fe& b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+ARKBP_HD Fe fe_dbl(const Fe& a) { return fe_add(a, a); }
+
+// a - b + K*p with K in {2,4,8,16}; borrow-free: the K*p limbs are pre-spread to be >= 2^31 - 4
+template <class P, int K> ARKBP_HD Fe fe_sub(const Fe& a, const Fe& b) {
+    static_assert(K == 2 || K == 4 || K == 8 || K == 16, "K");
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const u32 off = K == 2 ? P::SUBK2[i] : K == 4 ? P::SUBK4[i] : K == 8 ? P::SUBK8[i] : P::SUBK16[i];
+        ARKBP_ASSERT(i == 8 || a.l[i] <= (2u << 29), "fe_sub: L(a) > 2");
+        ARKBP_ASSERT(b.l[i] <= off, "fe_sub: limb of b exceeds the K*p offset");
+        r.l[i] = a.l[i] + off - b.l[i];
+    }
+    return fe_norm(r);
+}
+template <class P, int K> ARKBP_HD Fe fe_neg(const Fe& a) { return fe_sub<P, K>(fe_zero<P>(), a); }
+
+// Montgomery product a*b/2^261 mod p, column-wise with one 64-bit accumulator.
+template <class P> ARKBP_HD Fe fe_mul(const Fe& a, const Fe& b) {
+#ifdef ARKBP_CHECK_BOUNDS
+    { u64 la = 0, lb = 0; for (int i = 0; i < 9; i++) { if (a.l[i] > la) la = a.l[i]; if (b.l[i] > lb) lb = b.l[i]; }
+      ARKBP_ASSERT((unsigned __int128)la * lb <= ((unsigned __int128)6 << 58) + ((unsigned __int128)1 << 40), "fe_mul: L(a)*L(b) > 6"); }
+#endif
+    u32 m[9];
+    Fe t;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * P::P29[k - i];
+        m[k] = ((u32)acc * P::NINV29) & M29;
+        acc += (u64)m[k] * P::P29[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (u64)m[i] * P::P29[k - i];
+        t.l[k - 9] = (u32)acc & M29;
+        acc >>= 29;
+    }
+    ARKBP_ASSERT(acc < (1ull << 29), "fe_mul: result exceeds 2^261");
+    t.l[8] = (u32)acc;
+    return t;
+}
+
+// squaring: the 36 off-diagonal products are taken once against a doubled operand
+template <class P> ARKBP_HD Fe fe_sqr(const Fe& a) {
+    u32 m[9], a2[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
+#ifdef ARKBP_CHECK_BOUNDS
+    for (int i = 0; i < 9; i++) ARKBP_ASSERT(a.l[i] <= (2u << 29) + 16, "fe_sqr: L(a) > 2");
+#endif
+    Fe t;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (u64)a2[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * P::P29[k - i];
+        m[k] = ((u32)acc * P::NINV29) & M29;
+        acc += (u64)m[k] * P::P29[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) acc += (u64)a2[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (u64)m[i] * P::P29[k - i];
+        t.l[k - 9] = (u32)acc & M29;
+        acc >>= 29;
+    }
+    t.l[8] = (u32)acc;
+    return t;
+}
+
+// weak reduction: subtract floor-estimate(a / 2^WR_BITS) * p; needs L = 1 and a < 2^261.  Result <= 2p.
+template <class P> ARKBP_HD Fe fe_wred(const Fe& a) {
+    constexpr int sh = P::WR_BITS - 232;
+    u32 q = a.l[8] >> sh;
+    if (P::WR_SIGN > 0) q = q ? q - 1 : 0;  // p = 2^B + delta: q*p could exceed a, q-1 cannot
+    Fe r;
+    i64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc += (i64)a.l[i] - (i64)((u64)q * P::P29[i]);
+        r.l[i] = (u32)acc & M29;
+        acc >>= 29;  // arithmetic
+    }
+    ARKBP_ASSERT(acc == 0, "fe_wred: went negative or overflowed");
+    return r;
+}
+
+// full reduction to the canonical representative; input L = 1, V < 32
+template <class P> ARKBP_HD Fe fe_canon(const Fe& a) {
+    Fe w = fe_wred<P>(a);  // < 2p (+ tiny), so at most two subtractions of p
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        Fe d;
+        i32 c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            i32 t = (i32)w.l[i] - (i32)P::P29[i] + c;
+            d.l[i] = (u32)t & M29;
+            c = t >> 29;
+        }
+        const bool neg = c < 0;  // w < p
+#pragma unroll
+        for (int i = 0; i < 9; i++) w.l[i] = neg ? w.l[i] : d.l[i];
+    }
+    return w;
+}
+
+// a == 0 (mod p)?   Needs L = 1, V < 32.  Cheap filter on the low limb first: a = k*p forces
+// a_0 = k*p_0 mod 2^29 with k within one of the top-limb estimate; the exact test runs only then.
+template <class P> ARKBP_HD bool fe_is_zero_mod(const Fe& a) {
+    constexpr int sh = P::WR_BITS - 232;
+    const u32 q = a.l[8] >> sh;
+    bool maybe = false;
+#pragma unroll
+    for (int d = -1; d <= 1; d++) {
+        const u32 k = q + (u32)d;
+        maybe |= (a.l[0] == ((k * P::P29[0]) & M29));
+    }
+    if (!maybe) return false;
+    return fe_is_zero_exact(fe_canon<P>(a));
+}
+template <class P> ARKBP_HD bool fe_eq_mod(const Fe& a, const Fe& b) {  // L = 1 both, V(b) < 16
+    return fe_is_zero_mod<P>(fe_sub<P, 16>(a, b));
+}
+
+// ---- packing: 9 x 29-bit limbs <-> 8 x 32-bit words (value must be < 2^256) ----------------------
+ARKBP_HD void fe_pack(u32 w[8], const Fe& a) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i0 = (32 * j) / 29, o = 32 * j - 29 * i0;
+        u64 x = (u64)a.l[i0] | ((u64)a.l[i0 + 1] << 29);
+        if (i0 + 2 < 9 && 58 - o < 32) x |= (u64)a.l[i0 + 2] << 58;
+        w[j] = (u32)(x >> o);
+    }
+}
+ARKBP_HD Fe fe_unpack(const u32 w[8]) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int j0 = (29 * i) / 32, o = 29 * i - 32 * j0;
+        u64 x = (u64)w[j0];
+        if (j0 + 1 < 8) x |= (u64)w[j0 + 1] << 32;
+        r.l[i] = (u32)(x >> o) & M29;
+    }
+    return r;
+}
+
+// ark-ff Montgomery words (x*2^256 mod p) -> R' form, and back (canonical output words)
+template <class P> ARKBP_HD Fe fe_load_ark(const u32 w[8]) { return fe_mul<P>(fe_unpack(w), fe_const<P, P::TO29>()); }
+template <class P> ARKBP_HD void fe_store_ark(u32 w[8], const Fe& a) { fe_pack(w, fe_canon<P>(fe_mul<P>(a, fe_const<P, P::FROM29>()))); }
+// canonical integer words <-> R' form
+template <class P> ARKBP_HD Fe fe_load_canon(const u32 w[8]) { return fe_mul<P>(fe_unpack(w), fe_const<P, P::R2_29>()); }
+template <class P> ARKBP_HD void fe_store_canon(u32 w[8], const Fe& a) { fe_pack(w, fe_canon<P>(fe_mul<P>(a, fe_const<P, P::CANON29>()))); }
+// device-resident packed R' form (value < p)
+template <class P> ARKBP_HD Fe fe_load_dev(const u32 w[8]) { return fe_unpack(w); }
+template <class P> ARKBP_HD void fe_store_dev(u32 w[8], const Fe& a) { fe_pack(w, fe_canon<P>(a)); }
+
+// a^(p-2) (0 -> 0); input/outputs L = 1, V <= 2.  Off the per-element path: kernels batch inversions.
+template <class P> ARKBP_HD Fe fe_inv(const Fe& a) {
+    Fe r = fe_one<P>();
+#pragma unroll
+    for (int w = 7; w >= 0; w--) {
+        const u32 e = P::PM2[w];
+#pragma unroll 1
+        for (int i = 31; i >= 0; i--) {
+            r = fe_sqr<P>(r);
+            if ((e >> i) & 1) r = fe_mul<P>(r, a);
+        }
+    }
+    return r;
+}
+
+}  // namespace arkbp
