@@ -1,0 +1,54 @@
+"""ctypes binding of libarkbp_hip.so (include/arkbp.h).  Fails loudly when the HIP library is missing
+or no GPU is visible: there is no CPU fallback in the product path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarkbp_hip.so")
+_lib = None
+
+BP_OK, BP_E_ARG, BP_E_HIP, BP_E_NO_DEVICE, BP_E_VERIFICATION, BP_E_GENS_LENGTH, BP_E_FORMAT, BP_E_MISSING = 0, -1, -2, -3, -4, -5, -6, -7
+
+# every symbol include/arkbp.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "bp_last_error", "bp_device_count", "bp_ctx_create", "bp_ctx_destroy", "bp_ctx_sync",
+    "bp_dev_alloc", "bp_dev_free", "bp_dev_upload", "bp_dev_download", "bp_points_import", "bp_points_export",
+    "bp_msm", "bp_msm_dev", "bp_ctx_set_profiling", "bp_ctx_kernel_time", "bp_ctx_reset_profiling",
+    "bp_debug_field_op", "bp_debug_point_op",
+]
+
+
+class ArkbpError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().bp_last_error().decode(errors="replace") if _lib is not None else ""
+        super().__init__("%s failed with code %d: %s" % (where, code, msg))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libarkbp_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                "ark_bulletproofs_amd has no CPU fallback"
+            )
+        _lib = C.CDLL(LIB_PATH)
+        _lib.bp_last_error.restype = C.c_char_p
+    return _lib
+
+
+def check(rc, where):
+    if rc != BP_OK:
+        raise ArkbpError(rc, where)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def u64arr(a, width):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, width)

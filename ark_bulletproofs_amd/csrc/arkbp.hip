@@ -1,0 +1,388 @@
+// libarkbp_hip.so — context, workspaces, host orchestration and the C ABI (include/arkbp.h).
+// There is no CPU fallback: without a HIP device every compute entry point returns BP_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/arkbp.h"
+#include "host_math.hpp"
+#include "msm.cuh"
+
+using namespace arkbp;
+using arkbp::host::A4;
+using arkbp::host::F4;
+using arkbp::host::J4;
+
+static thread_local std::string g_err;
+const char* bp_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) {                                                                     \
+            g_err = std::string(#x) + ": " + hipGetErrorString(e_);                                 \
+            return BP_E_HIP;                                                                        \
+        }                                                                                           \
+    } while (0)
+#define BPCHK(x) do { int r_ = (x); if (r_ != BP_OK) return r_; } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return BP_OK;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return BP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() { return (T*)p; }
+};
+
+struct KTimer {
+    double ms = 0;
+    uint64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct bp_ctx {
+    int curve = 0, device = 0;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    KTimer timers[BP_K_COUNT];
+    std::vector<hipEvent_t> event_pool;
+    // MSM workspaces
+    DevBuf canon, hist, lvl_off, totals, cursor, entries, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
+    u32* h_totals = nullptr;  // pinned
+    u32* h_T = nullptr;       // pinned
+    size_t h_T_cap = 0;
+};
+
+static int get_event(bp_ctx* c, hipEvent_t* e) {
+    if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); return BP_OK; }
+    HIPCHK(hipEventCreate(e));
+    return BP_OK;
+}
+struct ScopedK {  // records start/stop events around a region when profiling is on
+    bp_ctx* c; int which; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+    ScopedK(bp_ctx* c_, int w) : c(c_), which(w), on(c_->profiling) {
+        if (on) { if (get_event(c, &e0) || get_event(c, &e1)) { on = false; return; } (void)hipEventRecord(e0, c->stream); }
+    }
+    void stop() { if (on) { (void)hipEventRecord(e1, c->stream); c->timers[which].pending.push_back({e0, e1}); on = false; } }
+    ~ScopedK() { stop(); }
+};
+static void collect_timers(bp_ctx* c) {
+    for (int k = 0; k < BP_K_COUNT; k++) {
+        for (auto& pr : c->timers[k].pending) {
+            float ms = 0;
+            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                c->timers[k].ms += ms; c->timers[k].launches++;
+            }
+            c->event_pool.push_back(pr.first); c->event_pool.push_back(pr.second);
+        }
+        c->timers[k].pending.clear();
+    }
+}
+
+// ---- MSM orchestration ---------------------------------------------------------------------------
+static MsmPlan msm_plan(size_t n, int bits) {
+    double best = 1e300; int bc = 4;
+    for (int c = 3; c <= 16; c++) {
+        double W = bits / c + 1, NBk = std::ldexp(1.0, c - 1), B = W * NBk;
+        double cost = n * W + (n * W / MSM_CH + B) * 1.45 + B * (0.5 * c) * 1.45 + 256.0 * c * W * 0.05;
+        if (cost < best) { best = cost; bc = c; }
+    }
+    MsmPlan pl; pl.c = bc; pl.W = bits / bc + 1; pl.NB = 1 << (bc - 1); pl.B = (u32)pl.W * pl.NB; pl.n = (u32)n;
+    return pl;
+}
+
+template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u32* d_scalars, size_t n, int scalars_mont, J4& result) {
+    typedef host::Grp<C> G;
+    typedef host::Fld<typename C::Fq> F;
+    result = G::inf();
+    if (n == 0) return BP_OK;
+    if (n >= (1u << 31)) { g_err = "msm: n too large"; return BP_E_ARG; }
+    hipStream_t st = ctx->stream;
+    MsmPlan pl = msm_plan(n, C::Fr::BITS);
+    constexpr int NL = MSM_MAXLVL + 1;
+    const size_t Bp1 = (size_t)pl.B + 1;
+    BPCHK(ctx->canon.ensure(n * 32));
+    BPCHK(ctx->hist.ensure(pl.B * 4));
+    BPCHK(ctx->lvl_off.ensure(Bp1 * NL * 4));
+    BPCHK(ctx->totals.ensure((NL + 1) * 4));
+    BPCHK(ctx->cursor.ensure(pl.B * 4));
+    BPCHK(ctx->entries.ensure(n * pl.W * 4));
+    BPCHK(ctx->Tbuf.ensure((size_t)pl.W * pl.c * 96));
+    if (!ctx->h_totals) HIPCHK(hipHostMalloc((void**)&ctx->h_totals, 64));
+    const size_t tbytes = (size_t)pl.W * pl.c * 96;
+    if (ctx->h_T_cap < tbytes) {
+        if (ctx->h_T) HIPCHK(hipHostFree(ctx->h_T));
+        HIPCHK(hipHostMalloc((void**)&ctx->h_T, tbytes + 4096));
+        ctx->h_T_cap = tbytes + 4096;
+    }
+    ScopedK total(ctx, BP_K_MSM_TOTAL);
+    u32* lvl = ctx->lvl_off.as<u32>();
+    HIPCHK(hipMemsetAsync(ctx->hist.p, 0, pl.B * 4, st));
+    const int TB = 256;
+    const u32 gb = (u32)((n + TB - 1) / TB);
+    hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont);
+    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ctx->hist.as<u32>(), lvl, ctx->totals.as<u32>(), pl.B);
+    HIPCHK(hipMemcpyAsync(ctx->cursor.p, lvl, pl.B * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_totals, ctx->totals.p, (NL + 1) * 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_msm_scatter, dim3(gb), dim3(TB), 0, st, ctx->canon.as<u32>(), ctx->cursor.as<u32>(), ctx->entries.as<u32>(), pl);
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    const u32* tot = ctx->h_totals;
+    const u32 maxcnt = tot[NL];
+    if (tot[0] == 0) { total.stop(); return BP_OK; }  // every digit zero: the identity
+    // levels: 1 = chunks of entries; k >= 2 = chunks of level k-1 partials; stop when a bucket holds <= 1
+    int K = 1;
+    { u64 cap = MSM_CH; while (cap < maxcnt) { cap *= MSM_CH; K++; } }
+    if (K > MSM_MAXLVL) { g_err = "msm: bucket population exceeds the reduction depth"; return BP_E_ARG; }
+    BPCHK(ctx->lvA.ensure((size_t)tot[1] * 96));
+    if (K >= 2) BPCHK(ctx->lvB.ensure((size_t)tot[2] * 96));
+    {
+        ScopedK acc(ctx, BP_K_MSM_ACCUM);
+        hipLaunchKernelGGL(k_msm_accum<C>, dim3((tot[1] + TB - 1) / TB), dim3(TB), 0, st, segs, ctx->entries.as<u32>(), lvl, lvl + Bp1,
+                           ctx->lvA.as<u32>(), pl.B, tot[1]);
+    }
+    u32* cur = ctx->lvA.as<u32>();
+    u32* nxt = ctx->lvB.as<u32>();
+    for (int k = 2; k <= K; k++) {
+        hipLaunchKernelGGL(k_msm_reduce<C>, dim3((tot[k] + TB - 1) / TB), dim3(TB), 0, st, cur, lvl + Bp1 * (k - 1), lvl + Bp1 * k, nxt, pl.B, tot[k]);
+        u32* t = cur; cur = nxt; nxt = t;
+    }
+    hipLaunchKernelGGL(k_msm_marginals<C>, dim3(pl.W, pl.c), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl);
+    HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tbytes, hipMemcpyDeviceToHost, st));
+    total.stop();
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    // host tail: sum_{w,k} 2^(c*w+k) T[w][k], Horner from the top bit down
+    J4 acc = G::inf();
+    const u64* T = (const u64*)ctx->h_T;
+    for (int j = pl.W * pl.c - 1; j >= 0; j--) {
+        acc = G::dbl(acc);
+        const u64* t = T + (size_t)j * 12;
+        J4 p; memcpy(p.X.v, t, 32); memcpy(p.Y.v, t + 4, 32); memcpy(p.Z.v, t + 8, 32);
+        if (!p.Z.is_zero()) acc = G::add(acc, p);
+    }
+    (void)sizeof(F);
+    result = acc;
+    return BP_OK;
+}
+
+template <class C> static void aff_out(uint64_t out[8], const A4& a) { memcpy(out, a.x.v, 32); memcpy(out + 4, a.y.v, 32); }
+
+template <class C> static int msm_dev_entry(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int canonical, uint64_t out_xy[8]) {
+    BaseSegs segs; memset(&segs, 0, sizeof segs);
+    segs.nseg = 1; segs.ptr[0] = (const u32*)d_bases; segs.start[0] = 0; segs.start[1] = (u32)n;
+    J4 r;
+    BPCHK(msm_run<C>(ctx, segs, (const u32*)d_scalars, n, canonical ? 0 : 1, r));
+    A4 a = host::Grp<C>::to_aff(r);
+    memcpy(out_xy, a.x.v, 32); memcpy(out_xy + 4, a.y.v, 32);
+    if (ctx->profiling) collect_timers(ctx);
+    return BP_OK;
+}
+
+// ---- unit-test kernels -----------------------------------------------------------------------------
+template <class F> __global__ void k_dbg_field(int op, const u32* a, const u32* b, u32* out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 wa[8], wb[8];
+    load_words8(wa, a + (size_t)i * 8); load_words8(wb, b + (size_t)i * 8);
+    Fe x = fe_load_ark<F>(wa), y = fe_load_ark<F>(wb), r;
+    switch (op) {
+        case 0: r = fe_mul<F>(x, y); break;
+        case 1: r = fe_norm(fe_add(x, y)); break;
+        case 2: r = fe_sub<F, 2>(x, y); break;
+        case 3: r = fe_sqr<F>(x); break;
+        default: r = fe_inv<F>(x); break;
+    }
+    fe_store_ark<F>(wa, r);
+    store_words8(out + (size_t)i * 8, wa);
+}
+template <class C> __global__ void k_dbg_point(int op, const u32* p, const u32* q, const u32* k, u32* out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[16];
+    load_words8(w, p + (size_t)i * 16); load_words8(w + 8, p + (size_t)i * 16 + 8);
+    Aff P = aff_load_ark<C>(w);
+    load_words8(w, q + (size_t)i * 16); load_words8(w + 8, q + (size_t)i * 16 + 8);
+    Aff Q = aff_load_ark<C>(w);
+    Jac r;
+    if (op == 0) r = jac_add<C>(jac_from_aff<C>(P), jac_from_aff<C>(Q));
+    else if (op == 1) r = jac_madd<C>(jac_from_aff<C>(P), Q);
+    else if (op == 2) r = jac_dbl<C>(jac_from_aff<C>(P));
+    else {
+        u32 kk[8];
+        load_words8(kk, k + (size_t)i * 8);
+        r = jac_inf<C>();
+        for (int b = 255; b >= 0; b--) {
+            r = jac_dbl<C>(r);
+            if ((kk[b >> 5] >> (b & 31)) & 1) r = jac_madd<C>(r, P);
+        }
+    }
+    Aff a = jac_to_aff<C>(r);
+    aff_store_ark<C>(w, a);
+    store_words8(out + (size_t)i * 16, w); store_words8(out + (size_t)i * 16 + 8, w + 8);
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------
+extern "C" {
+
+int bp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bp_ctx_create(int curve, int device, bp_ctx** out) {
+    if (!out || (curve != BP_CURVE_SECQ256K1 && curve != BP_CURVE_ZORRO)) { g_err = "bp_ctx_create: bad argument"; return BP_E_ARG; }
+    int n = bp_device_count();
+    if (n <= 0 || device < 0 || device >= n) { g_err = "bp_ctx_create: no HIP device (the engine has no CPU fallback)"; return BP_E_NO_DEVICE; }
+    HIPCHK(hipSetDevice(device));
+    bp_ctx* c = new bp_ctx();
+    c->curve = curve; c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; g_err = hipGetErrorString(e); return BP_E_HIP; }
+    *out = c;
+    return BP_OK;
+}
+void bp_ctx_destroy(bp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    collect_timers(c);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out};
+    for (auto b : bufs) b->release();
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
+    if (c->h_T) (void)hipHostFree(c->h_T);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+int bp_ctx_sync(bp_ctx* c) {
+    if (!c) return BP_E_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BP_OK;
+}
+
+int bp_dev_alloc(bp_ctx* c, size_t bytes, void** dptr) {
+    if (!c || !dptr) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 1));
+    return BP_OK;
+}
+int bp_dev_free(bp_ctx* c, void* dptr) {
+    if (!c) return BP_E_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(dptr));
+    return BP_OK;
+}
+int bp_dev_upload(bp_ctx* c, void* dptr, const void* hostp, size_t bytes) {
+    if (!c || (!dptr && bytes) || (!hostp && bytes)) return BP_E_ARG;
+    HIPCHK(hipMemcpyAsync(dptr, hostp, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BP_OK;
+}
+int bp_dev_download(bp_ctx* c, void* hostp, const void* dptr, size_t bytes) {
+    if (!c || (!dptr && bytes) || (!hostp && bytes)) return BP_E_ARG;
+    HIPCHK(hipMemcpyAsync(hostp, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BP_OK;
+}
+int bp_points_import(bp_ctx* c, const void* d_in, void* d_out, size_t n) {
+    if (!c || ((!d_in || !d_out) && n)) return BP_E_ARG;
+    if (!n) return BP_OK;
+    const u32 gb = (u32)((n + 255) / 256);
+    if (c->curve == 0) hipLaunchKernelGGL(k_points_ark_to_dev<Secq>, dim3(gb), dim3(256), 0, c->stream, (const u32*)d_in, (u32*)d_out, (u32)n);
+    else hipLaunchKernelGGL(k_points_ark_to_dev<Zorro>, dim3(gb), dim3(256), 0, c->stream, (const u32*)d_in, (u32*)d_out, (u32)n);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+int bp_points_export(bp_ctx* c, const void* d_in, void* d_out, size_t n) {
+    if (!c || ((!d_in || !d_out) && n)) return BP_E_ARG;
+    if (!n) return BP_OK;
+    const u32 gb = (u32)((n + 255) / 256);
+    if (c->curve == 0) hipLaunchKernelGGL(k_points_dev_to_ark<Secq>, dim3(gb), dim3(256), 0, c->stream, (const u32*)d_in, (u32*)d_out, (u32)n);
+    else hipLaunchKernelGGL(k_points_dev_to_ark<Zorro>, dim3(gb), dim3(256), 0, c->stream, (const u32*)d_in, (u32*)d_out, (u32)n);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
+int bp_msm_dev(bp_ctx* c, const void* d_bases, const void* d_scalars, size_t n, int canonical, uint64_t out_xy[8]) {
+    if (!c || !out_xy || ((!d_bases || !d_scalars) && n)) { g_err = "bp_msm_dev: bad argument"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? msm_dev_entry<Secq>(c, d_bases, d_scalars, n, canonical, out_xy) : msm_dev_entry<Zorro>(c, d_bases, d_scalars, n, canonical, out_xy);
+}
+int bp_msm(bp_ctx* c, const uint64_t* bases_xy, const uint64_t* scalars, size_t n, int canonical, uint64_t out_xy[8]) {
+    if (!c || !out_xy || ((!bases_xy || !scalars) && n)) { g_err = "bp_msm: bad argument"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) { memset(out_xy, 0, 64); return BP_OK; }
+    BPCHK(c->io_pts.ensure(n * 64));
+    BPCHK(c->io_scal.ensure(n * 32));
+    HIPCHK(hipMemcpyAsync(c->io_pts.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->io_scal.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    BPCHK(bp_points_import(c, c->io_pts.p, c->io_pts.p, n));
+    return bp_msm_dev(c, c->io_pts.p, c->io_scal.p, n, canonical, out_xy);
+}
+
+int bp_ctx_set_profiling(bp_ctx* c, int enabled) { if (!c) return BP_E_ARG; c->profiling = enabled != 0; return BP_OK; }
+int bp_ctx_kernel_time(bp_ctx* c, int which, double* ms_total, uint64_t* launches) {
+    if (!c || which < 0 || which >= BP_K_COUNT) return BP_E_ARG;
+    collect_timers(c);
+    if (ms_total) *ms_total = c->timers[which].ms;
+    if (launches) *launches = c->timers[which].launches;
+    return BP_OK;
+}
+int bp_ctx_reset_profiling(bp_ctx* c) {
+    if (!c) return BP_E_ARG;
+    collect_timers(c);
+    for (int k = 0; k < BP_K_COUNT; k++) { c->timers[k].ms = 0; c->timers[k].launches = 0; }
+    return BP_OK;
+}
+
+int bp_debug_field_op(bp_ctx* c, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!c || !a || !b || !out || field < 0 || field > 3) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    BPCHK(c->io_pts.ensure(n * 32)); BPCHK(c->io_scal.ensure(n * 32)); BPCHK(c->io_out.ensure(n * 32));
+    HIPCHK(hipMemcpyAsync(c->io_pts.p, a, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->io_scal.p, b, n * 32, hipMemcpyHostToDevice, c->stream));
+    const u32 gb = (u32)((n + 63) / 64);
+    const u32 *pa = c->io_pts.as<u32>(), *pb = c->io_scal.as<u32>();
+    u32* po = c->io_out.as<u32>();
+    switch (field) {
+        case 0: hipLaunchKernelGGL(k_dbg_field<SecqFq>, dim3(gb), dim3(64), 0, c->stream, op, pa, pb, po, (u32)n); break;
+        case 1: hipLaunchKernelGGL(k_dbg_field<SecqFr>, dim3(gb), dim3(64), 0, c->stream, op, pa, pb, po, (u32)n); break;
+        case 2: hipLaunchKernelGGL(k_dbg_field<ZorroFq>, dim3(gb), dim3(64), 0, c->stream, op, pa, pb, po, (u32)n); break;
+        default: hipLaunchKernelGGL(k_dbg_field<ZorroFr>, dim3(gb), dim3(64), 0, c->stream, op, pa, pb, po, (u32)n); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, po, n * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BP_OK;
+}
+int bp_debug_point_op(bp_ctx* c, int op, const uint64_t* p, const uint64_t* q, const uint64_t* k, uint64_t* out, size_t n) {
+    if (!c || !p || !q || !k || !out) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    BPCHK(c->io_pts.ensure(n * 128)); BPCHK(c->io_scal.ensure(n * 32)); BPCHK(c->io_out.ensure(n * 64));
+    u32* dp = c->io_pts.as<u32>();
+    u32* dq = dp + n * 16;
+    HIPCHK(hipMemcpyAsync(dp, p, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dq, q, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->io_scal.p, k, n * 32, hipMemcpyHostToDevice, c->stream));
+    const u32 gb = (u32)((n + 63) / 64);
+    if (c->curve == 0) hipLaunchKernelGGL(k_dbg_point<Secq>, dim3(gb), dim3(64), 0, c->stream, op, dp, dq, c->io_scal.as<u32>(), c->io_out.as<u32>(), (u32)n);
+    else hipLaunchKernelGGL(k_dbg_point<Zorro>, dim3(gb), dim3(64), 0, c->stream, op, dp, dq, c->io_scal.as<u32>(), c->io_out.as<u32>(), (u32)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+// Variable-base multi-scalar multiplication on gfx950 — the device replacement for every
+// `G::Group::msm(&bases, &scalars)` call of the reference (ark-ec VariableBaseMSM; call sites
+// src/inner_product_proof.rs:104,124,187,202,375; src/r1cs/prover.rs:516,532,546,607,622,635;
+// src/r1cs/verifier.rs:574,685).  The result is a group element, so any correct schedule gives the
+// affine coordinates ark produces; this one is laid out for 256 CUs x 64-lane waves:
+//
+//   1. k_msm_digits    signed c-bit digits of every scalar (ark Montgomery or canonical words in HBM),
+//                      per-(window,|digit|) histogram (global atomics, buckets >> lanes for random data)
+//   2. k_msm_scan      exclusive scans: entry offsets + chunk offsets for every reduction level
+//   3. k_msm_scatter   counting-sort scatter of (term index, sign) into bucket order
+//   4. k_msm_accum     level 1: one lane per CH-entry chunk of a bucket, mixed Jacobian+affine adds of
+//                      gathered 64-byte bases.  Chunking (not "one lane per bucket") keeps skewed inputs
+//                      balanced: 0/1 witness vectors put every term of a window in ONE bucket.
+//   5. k_msm_reduce    levels 2..K: CH-ary tree over the per-chunk partial sums until one point per bucket
+//   6. k_msm_marginals one 256-lane workgroup per (window w, bit k): sum of the buckets whose value has bit
+//                      k set, LDS tree.  sum_w sum_v v*B[w][v] = sum_{w,k} 2^(c*w+k) * T[w][k]
+//   7. host            the <= 280-term Horner over T (256 doublings of ONE point: a serial chain that a
+//                      2.4 GHz scalar core runs ~40x faster than a single GPU lane).
+//
+// Algorithmic bytes: 96 B per term (64 B affine base + 32 B scalar), SURVEY.md §8(d).
+#pragma once
+#include "ec.cuh"
+
+namespace arkbp {
+
+static constexpr int MSM_CH = 16;      // entries per level-1 lane / fan-in of the reduction tree
+static constexpr int MSM_MAXLVL = 8;   // 16^8 = 2^32 >= any bucket population
+static constexpr int MSM_MAXSEG = 4;
+
+// A logical base vector made of up to 4 device-resident segments (e.g. G_R || H_L || Q) — the
+// reference materialises such concatenations into fresh Vecs (src/inner_product_proof.rs:86-91).
+struct BaseSegs {
+    const u32* ptr[MSM_MAXSEG];   // 16 words per point, packed R' form (aff_store_dev)
+    u32 start[MSM_MAXSEG + 1];    // prefix counts; start[nseg] = n
+    int nseg;
+};
+__device__ __forceinline__ const u32* seg_base_ptr(const BaseSegs& s, u32 idx) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MSM_MAXSEG; j++) k += (j < s.nseg && idx >= s.start[j]) ? 1 : 0;
+    return s.ptr[k] + (size_t)(idx - s.start[k]) * 16;
+}
+
+struct MsmPlan {
+    int c, W, NB;        // window bits, windows, buckets per window (2^(c-1))
+    u32 B;               // W * NB
+    u32 n;
+};
+
+__device__ __forceinline__ void load_words8(u32 w[8], const u32* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store_words8(u32* p, const u32 w[8]) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ Aff load_aff_dev(const u32* p) {
+    u32 w[16];
+    load_words8(w, p);
+    load_words8(w + 8, p + 8);
+    return aff_load_dev(w);
+}
+// Jacobian points in workspace: 3 x 8 words, canonical R' form; Z == 0 words <=> identity
+template <class C> __device__ __forceinline__ void store_jac_ws(u32* p, const Jac& j) {
+    typedef typename C::Fq F;
+    u32 w[8];
+    fe_pack(w, fe_canon<F>(j.X)); store_words8(p, w);
+    fe_pack(w, fe_canon<F>(j.Y)); store_words8(p + 8, w);
+    fe_pack(w, fe_canon<F>(j.Z)); store_words8(p + 16, w);
+}
+__device__ __forceinline__ Jac load_jac_ws(const u32* p) {
+    u32 w[8];
+    Jac j;
+    load_words8(w, p); j.X = fe_unpack(w);
+    load_words8(w, p + 8); j.Y = fe_unpack(w);
+    load_words8(w, p + 16); j.Z = fe_unpack(w);
+    return j;
+}
+
+// signed digit w of a canonical scalar (8 words), carry in/out; |d| <= 2^(c-1)
+__device__ __forceinline__ int msm_digit(const u32 k[8], int w, int c, u32& carry) {
+    const int bit = w * c;
+    const int wi = bit >> 5, bo = bit & 31;
+    u64 x = 0;
+    if (wi < 8) x = k[wi];
+    if (wi + 1 < 8) x |= (u64)k[wi + 1] << 32;
+    u32 d = ((u32)(x >> bo) & ((1u << c) - 1)) + carry;
+    carry = d > (1u << (c - 1)) ? 1u : 0u;
+    return (int)d - (int)(carry << c);
+}
+
+// 1. digits + histogram.  scalars_mont: words are ark Montgomery form (R = 2^256), else canonical.
+template <class C> __global__ void k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl,
+                                                int scalars_mont) {
+    typedef typename C::Fr Fr;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pl.n) return;
+    u32 k[8];
+    load_words8(k, scalars + (size_t)i * 8);
+    if (scalars_mont) {
+        Fe s = fe_load_ark<Fr>(k);
+        fe_store_canon<Fr>(k, s);
+    }
+    store_words8(canon + (size_t)i * 8, k);
+    u32 carry = 0;
+    for (int w = 0; w < pl.W; w++) {
+        int d = msm_digit(k, w, pl.c, carry);
+        if (d != 0) atomicAdd(&hist[(u32)w * pl.NB + (u32)(d < 0 ? -d : d) - 1], 1u);
+    }
+}
+
+// 2. scans.  lvl_off[k] (k = 0..MAXLVL) has B+1 entries: level 0 counts entries, level k >= 1 counts
+// ceil(cnt / CH^k) chunks.  totals[k] = lvl_off[k][B]; totals[MAXLVL+1] = max bucket population.
+__global__ void k_msm_scan(const u32* __restrict__ hist, u32* __restrict__ lvl_off, u32* __restrict__ totals, u32 B) {
+    constexpr int NL = MSM_MAXLVL + 1;
+    __shared__ u32 sh[1024][NL + 1];
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u32 per = (B + nt - 1) / nt;
+    const u32 lo = min(B, tid * per), hi = min(B, lo + per);
+    u32 sum[NL], mx = 0;
+    for (int k = 0; k < NL; k++) sum[k] = 0;
+    for (u32 b = lo; b < hi; b++) {
+        u32 cnt = hist[b];
+        mx = max(mx, cnt);
+        u32 v = cnt;
+        for (int k = 0; k < NL; k++) { sum[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
+    }
+    for (int k = 0; k < NL; k++) sh[tid][k] = sum[k];
+    sh[tid][NL] = mx;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over threads (1024 x NL words; runs once per MSM)
+    for (u32 d = 1; d < nt; d <<= 1) {
+        u32 tmp[NL + 1];
+        const bool has = tid >= d;
+        for (int k = 0; k < NL; k++) tmp[k] = has ? sh[tid - d][k] : 0;
+        tmp[NL] = has ? sh[tid - d][NL] : 0;
+        __syncthreads();
+        for (int k = 0; k < NL; k++) sh[tid][k] += tmp[k];
+        sh[tid][NL] = max(sh[tid][NL], tmp[NL]);
+        __syncthreads();
+    }
+    u32 run[NL];
+    for (int k = 0; k < NL; k++) run[k] = tid ? sh[tid - 1][k] : 0;
+    for (u32 b = lo; b < hi; b++) {
+        u32 v = hist[b];
+        for (int k = 0; k < NL; k++) { lvl_off[(size_t)k * (B + 1) + b] = run[k]; run[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
+    }
+    if (tid == nt - 1) {
+        for (int k = 0; k < NL; k++) { lvl_off[(size_t)k * (B + 1) + B] = sh[tid][k]; totals[k] = sh[tid][k]; }
+        totals[NL] = sh[tid][NL];
+    }
+}
+
+// 3. scatter into bucket order.  cursor starts as a copy of lvl_off[0].
+__global__ void k_msm_scatter(const u32* __restrict__ canon, u32* __restrict__ cursor, u32* __restrict__ entries, MsmPlan pl) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pl.n) return;
+    u32 k[8];
+    load_words8(k, canon + (size_t)i * 8);
+    u32 carry = 0;
+    for (int w = 0; w < pl.W; w++) {
+        int d = msm_digit(k, w, pl.c, carry);
+        if (d != 0) {
+            u32 pos = atomicAdd(&cursor[(u32)w * pl.NB + (u32)(d < 0 ? -d : d) - 1], 1u);
+            entries[pos] = (i << 1) | (d < 0 ? 1u : 0u);
+        }
+    }
+}
+
+// largest b with off[b] <= j   (off has B+1 monotone entries, off[B] > j)
+__device__ __forceinline__ u32 find_bucket(const u32* __restrict__ off, u32 B, u32 j) {
+    u32 lo = 0, hi = B;  // invariant: off[lo] <= j < off[hi]
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (off[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// 4. level 1: lane j sums the j-th CH-entry chunk (mixed adds of gathered affine bases)
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restrict__ off0, const u32* __restrict__ off1, u32* __restrict__ out,
+            u32 B, u32 nchunks) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nchunks) return;
+    const u32 b = find_bucket(off1, B, j);
+    const u32 beg = off0[b] + (j - off1[b]) * MSM_CH;
+    const u32 end = min(beg + MSM_CH, off0[b + 1]);
+    Jac acc = jac_inf<C>();
+    for (u32 e = beg; e < end; e++) {
+        const u32 ent = entries[e];
+        Aff p = load_aff_dev(seg_base_ptr(segs, ent >> 1));
+        acc = jac_madd<C>(acc, aff_cneg_lazy<C>(p, ent & 1));
+    }
+    store_jac_ws<C>(out + (size_t)j * 24, acc);
+}
+
+// 5. level k >= 2: lane j sums chunk j of level k-1 partials
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_reduce(const u32* __restrict__ in, const u32* __restrict__ off_prev, const u32* __restrict__ off_cur, u32* __restrict__ out, u32 B,
+             u32 nchunks) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nchunks) return;
+    const u32 b = find_bucket(off_cur, B, j);
+    const u32 beg = off_prev[b] + (j - off_cur[b]) * MSM_CH;
+    const u32 end = min(beg + MSM_CH, off_prev[b + 1]);
+    Jac acc = load_jac_ws(in + (size_t)beg * 24);
+    for (u32 e = beg + 1; e < end; e++) acc = jac_add<C>(acc, load_jac_ws(in + (size_t)e * 24));
+    store_jac_ws<C>(out + (size_t)j * 24, acc);
+}
+
+// 6. marginal sums: block (w, k) adds every bucket of window w whose value v = idx+1 has bit k set.
+// `off` is the last level's offsets (<= 1 partial per bucket).  Output: Jacobian, ark Montgomery words
+// (3 x 8 words) so the host tail reads them directly.
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_marginals(const u32* __restrict__ sums, const u32* __restrict__ off, u32* __restrict__ T_out, MsmPlan pl) {
+    typedef typename C::Fq F;
+    __shared__ u32 sh[256 * 27];
+    const int w = blockIdx.x, k = blockIdx.y;
+    const u32 tid = threadIdx.x;
+    Jac acc = jac_inf<C>();
+    for (u32 idx = tid; idx < (u32)pl.NB; idx += 256) {
+        if (!(((idx + 1) >> k) & 1)) continue;
+        const u32 b = (u32)w * pl.NB + idx;
+        const u32 o = off[b];
+        if (off[b + 1] == o) continue;  // empty bucket
+        acc = jac_add<C>(acc, load_jac_ws(sums + (size_t)o * 24));
+    }
+    // LDS tree: limbs stored limb-major (27 rows of 256 words) so lanes hit distinct banks
+    for (u32 stride = 128; stride >= 1; stride >>= 1) {
+        if (tid >= stride && tid < 2 * stride) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) { sh[i * 256 + tid] = acc.X.l[i]; sh[(9 + i) * 256 + tid] = acc.Y.l[i]; sh[(18 + i) * 256 + tid] = acc.Z.l[i]; }
+        }
+        __syncthreads();
+        if (tid < stride) {
+            Jac o;
+#pragma unroll
+            for (int i = 0; i < 9; i++) { o.X.l[i] = sh[i * 256 + tid + stride]; o.Y.l[i] = sh[(9 + i) * 256 + tid + stride]; o.Z.l[i] = sh[(18 + i) * 256 + tid + stride]; }
+            acc = jac_add<C>(acc, o);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        u32* o = T_out + ((size_t)w * pl.c + k) * 24;
+        u32 wd[8];
+        const bool inf = jac_is_inf(acc);
+        fe_store_ark<F>(wd, acc.X); store_words8(o, wd);
+        fe_store_ark<F>(wd, acc.Y); store_words8(o + 8, wd);
+        if (inf) { for (int i = 0; i < 8; i++) wd[i] = 0; } else fe_store_ark<F>(wd, acc.Z);
+        store_words8(o + 16, wd);
+    }
+}
+
+// ---- format conversion kernels -------------------------------------------------------------------
+// ark layout (x||y Montgomery R=2^256, identity = zeros) -> device layout (packed R' form)
+template <class C> __global__ void k_points_ark_to_dev(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[16];
+    load_words8(w, in + (size_t)i * 16);
+    load_words8(w + 8, in + (size_t)i * 16 + 8);
+    Aff p = aff_load_ark<C>(w);
+    u32 o[16];
+    aff_store_dev(o, p);
+    store_words8(out + (size_t)i * 16, o);
+    store_words8(out + (size_t)i * 16 + 8, o + 8);
+}
+template <class C> __global__ void k_points_dev_to_ark(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff p = load_aff_dev(in + (size_t)i * 16);
+    u32 o[16];
+    aff_store_ark<C>(o, p);
+    store_words8(out + (size_t)i * 16, o);
+    store_words8(out + (size_t)i * 16 + 8, o + 8);
+}
+
+}  // namespace arkbp

@@ -1,0 +1,112 @@
+"""Engine: one bp_ctx (one GPU, one HIP stream) and typed wrappers over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, ptr, u64arr
+
+SECQ256K1, ZORRO = 0, 1
+
+
+class DeviceBuffer:
+    """HBM allocation owned by an Engine."""
+
+    def __init__(self, eng, nbytes):
+        self.eng, self.nbytes = eng, nbytes
+        p = C.c_void_p()
+        check(lib().bp_dev_alloc(eng.ctx, C.c_size_t(nbytes), C.byref(p)), "bp_dev_alloc")
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(lib().bp_dev_upload(self.eng.ctx, self.ptr, ptr(arr), C.c_size_t(arr.nbytes)), "bp_dev_upload")
+        return self
+
+    def download(self, dtype=np.uint64, nbytes=None):
+        nbytes = self.nbytes if nbytes is None else nbytes
+        out = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        check(lib().bp_dev_download(self.eng.ctx, ptr(out), self.ptr, C.c_size_t(nbytes)), "bp_dev_download")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().bp_dev_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+
+class Engine:
+    def __init__(self, curve=SECQ256K1, device=0):
+        self.curve = curve
+        self.ctx = C.c_void_p()
+        check(lib().bp_ctx_create(curve, device, C.byref(self.ctx)), "bp_ctx_create")
+
+    def close(self):
+        if self.ctx:
+            lib().bp_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory -------------------------------------------------------------------------------
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload_points(self, pts_xy):
+        """ark-layout affine points (n x 8 u64) -> resident engine layout"""
+        pts = u64arr(pts_xy, 8)
+        buf = DeviceBuffer(self, max(pts.nbytes, 64)).upload(pts)
+        check(lib().bp_points_import(self.ctx, buf.ptr, buf.ptr, C.c_size_t(len(pts))), "bp_points_import")
+        return buf
+
+    def upload_scalars(self, scalars):
+        sc = u64arr(scalars, 4)
+        return DeviceBuffer(self, max(sc.nbytes, 32)).upload(sc)
+
+    def sync(self):
+        check(lib().bp_ctx_sync(self.ctx), "bp_ctx_sync")
+
+    # ---- VariableBaseMSM::msm -------------------------------------------------------------------
+    def msm(self, bases_xy, scalars, canonical=False):
+        b, s = u64arr(bases_xy, 8), u64arr(scalars, 4)
+        if len(b) != len(s):
+            raise ValueError("msm: %d bases vs %d scalars" % (len(b), len(s)))  # ark: Err(min_len)
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().bp_msm(self.ctx, ptr(b), ptr(s), C.c_size_t(len(b)), int(canonical), ptr(out)), "bp_msm")
+        return out
+
+    def msm_dev(self, d_bases, d_scalars, n, canonical=False):
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().bp_msm_dev(self.ctx, d_bases.ptr, d_scalars.ptr, C.c_size_t(n), int(canonical), ptr(out)), "bp_msm_dev")
+        return out
+
+    # ---- profiling ------------------------------------------------------------------------------
+    def set_profiling(self, on=True):
+        check(lib().bp_ctx_set_profiling(self.ctx, int(on)), "bp_ctx_set_profiling")
+
+    def reset_profiling(self):
+        check(lib().bp_ctx_reset_profiling(self.ctx), "bp_ctx_reset_profiling")
+
+    def kernel_time(self, which):
+        ms, cnt = C.c_double(0), C.c_uint64(0)
+        check(lib().bp_ctx_kernel_time(self.ctx, which, C.byref(ms), C.byref(cnt)), "bp_ctx_kernel_time")
+        return ms.value, cnt.value
+
+    # ---- unit-test hooks ---------------------------------------------------------------------------
+    def debug_field_op(self, field, op, a, b):
+        a, b = u64arr(a, 4), u64arr(b, 4)
+        out = np.zeros_like(a)
+        check(lib().bp_debug_field_op(self.ctx, field, op, ptr(a), ptr(b), ptr(out), C.c_size_t(len(a))), "bp_debug_field_op")
+        return out
+
+    def debug_point_op(self, op, p, q, k=None):
+        p, q = u64arr(p, 8), u64arr(q, 8)
+        k = np.zeros((len(p), 4), dtype=np.uint64) if k is None else u64arr(k, 4)
+        out = np.zeros_like(p)
+        check(lib().bp_debug_point_op(self.ctx, op, ptr(p), ptr(q), ptr(k), ptr(out), C.c_size_t(len(p))), "bp_debug_point_op")
+        return out

@@ -1,0 +1,85 @@
+/* arkbp.h — C ABI of libarkbp_hip.so: the MI355X (gfx950) engine behind the MSM / inner-product hot path of
+ * FindoraNetwork/ark-bulletproofs.  Every entry point names the reference interface it replaces
+ * (paths are into the reference repository).  A Rust shim binds these with `extern "C"`
+ * (see INTEGRATION.md); the repo's own tests bind them with ctypes.
+ *
+ * Data conventions (identical to the reference's in-memory types, so a shim passes pointers):
+ *   field element  4 x uint64_t little-endian limbs, Montgomery form with R = 2^256 — ark-ff's
+ *                  Fp256<MontBackend<_,4>>.  "scalar" = element of G::ScalarField, coordinates are in
+ *                  the curve's base field.
+ *   affine point   8 x uint64_t = x || y.  ark's Affine{x,y,infinity} packs to this with the identity
+ *                  encoded as all-zero (0,0 is on neither curve).
+ *   curve          0 = secq256k1 (ark-secq256k1), 1 = zorro (src/curve/zorro/)
+ * All functions return 0 on success or a negative BP_E_* code; nothing throws or aborts across the
+ * boundary.  A bp_ctx owns one HIP stream and its workspaces: calls on one ctx are serialised, distinct
+ * contexts are independent (one per device / host thread).
+ */
+#ifndef ARKBP_H
+#define ARKBP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BP_CURVE_SECQ256K1 0
+#define BP_CURVE_ZORRO 1
+
+#define BP_OK 0
+#define BP_E_ARG (-1)          /* bad argument (null pointer, unknown curve, length mismatch) */
+#define BP_E_HIP (-2)          /* HIP runtime error; bp_last_error() has the text */
+#define BP_E_NO_DEVICE (-3)    /* no gfx950 device visible: the engine has no CPU fallback */
+#define BP_E_VERIFICATION (-4) /* R1CSError::VerificationError / ProofError::VerificationError (src/errors.rs) */
+#define BP_E_GENS_LENGTH (-5)  /* R1CSError::InvalidGeneratorsLength */
+#define BP_E_FORMAT (-6)       /* R1CSError::FormatError */
+#define BP_E_MISSING (-7)      /* R1CSError::MissingAssignment */
+
+typedef struct bp_ctx bp_ctx;
+
+const char* bp_last_error(void);
+/* number of HIP devices visible (0 => every compute entry point returns BP_E_NO_DEVICE) */
+int bp_device_count(void);
+int bp_ctx_create(int curve, int device, bp_ctx** out);
+void bp_ctx_destroy(bp_ctx* ctx);
+int bp_ctx_sync(bp_ctx* ctx);
+
+/* ---- device memory (HBM-resident vectors, so repeated calls do not re-cross PCIe) ---------------- */
+int bp_dev_alloc(bp_ctx* ctx, size_t bytes, void** dptr);
+int bp_dev_free(bp_ctx* ctx, void* dptr);
+int bp_dev_upload(bp_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int bp_dev_download(bp_ctx* ctx, void* host, const void* dptr, size_t bytes);
+/* affine points, ark layout -> the engine's resident layout (64 B/point, radix-2^29 Montgomery, packed),
+ * device to device; in == out is allowed.  bp_points_export is the inverse. */
+int bp_points_import(bp_ctx* ctx, const void* d_in_ark, void* d_out, size_t n);
+int bp_points_export(bp_ctx* ctx, const void* d_in, void* d_out_ark, size_t n);
+
+/* ---- VariableBaseMSM::msm -------------------------------------------------------------------------
+ * Replaces `<G::Group as VariableBaseMSM>::msm(&bases, &scalars).unwrap().into_affine()`
+ * (src/inner_product_proof.rs:104,124,187,202,375; src/r1cs/prover.rs:516,532,546,607,622,635;
+ *  src/r1cs/verifier.rs:574,685 — the verifier only tests `is_zero()`, i.e. out == all-zero).
+ * Host buffers: bases_xy n points (ark layout), scalars n field elements (Montgomery, or canonical
+ * integers if scalars_canonical != 0 — what ark's msm_bigint takes).  out_xy = affine result. */
+int bp_msm(bp_ctx* ctx, const uint64_t* bases_xy, const uint64_t* scalars, size_t n, int scalars_canonical, uint64_t out_xy[8]);
+/* Same with operands already resident: d_bases in the engine's layout (bp_points_import), d_scalars n x
+ * 32 B.  This is the call the timed region of bench.py makes. */
+int bp_msm_dev(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int scalars_canonical, uint64_t out_xy[8]);
+
+/* ---- profiling: HIP-event time of the dominant kernel of the last call, on the ctx stream ---------- */
+#define BP_K_MSM_ACCUM 0   /* bucket accumulation (k_msm_accum) */
+#define BP_K_MSM_TOTAL 1   /* all MSM kernels of the call, first launch to last */
+#define BP_K_COUNT 8
+int bp_ctx_set_profiling(bp_ctx* ctx, int enabled);
+/* accumulated milliseconds and launch count since the last reset */
+int bp_ctx_kernel_time(bp_ctx* ctx, int which, double* ms_total, uint64_t* launches);
+int bp_ctx_reset_profiling(bp_ctx* ctx);
+
+/* ---- unit-test hooks: one field / group operation per element on the GPU -------------------------- */
+/* field: 2*curve + (0 base field | 1 scalar field); op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inv */
+int bp_debug_field_op(bp_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* op: 0 P+Q (general add), 1 P+Q (mixed add), 2 2P, 3 k*P (k canonical, one per element) */
+int bp_debug_point_op(bp_ctx* ctx, int op, const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* k, uint64_t* out_xy, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

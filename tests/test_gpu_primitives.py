@@ -1,0 +1,135 @@
+"""GPU parity tests, through the C ABI, of the kernels' field / group arithmetic and the MSM against the
+CPU oracle on the same seeded inputs (bit-exact: integer work)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[0, 1], ids=["secq256k1", "zorro"])
+def eng(request):
+    import ark_bulletproofs_amd as A
+
+    e = A.Engine(curve=request.param)
+    yield e
+    e.close()
+
+
+def test_field_ops(eng, oracle):
+    O = oracle
+    n = 300
+    for sf in (False, True):
+        f = O.fid(eng.curve, sf)
+        a = O.fe_rand(f, bytes([11]) * 32, n)
+        b = O.fe_rand(f, bytes([12]) * 32, n)
+        p = O.modulus(f)
+        for i, v in enumerate([0, 1, p - 1, p - 2, 2, (1 << 255) % p]):
+            a[i] = O.fe_from_int(f, v)
+            b[i] = O.fe_from_int(f, [p - 1, 0, p - 1, 1, p - 2, 3][i])
+        for op, name in [(0, "mul"), (1, "add"), (2, "sub")]:
+            got = eng.debug_field_op(f, op, a, b)
+            exp = np.array([O.fe_op(name, f, a[i], b[i]) for i in range(n)])
+            assert (got == exp).all(), name
+        got = eng.debug_field_op(f, 3, a, b)
+        assert (got == np.array([O.fe_op("mul", f, a[i], a[i]) for i in range(n)])).all()
+        got = eng.debug_field_op(f, 4, a[2:66], b[2:66])
+        assert (got == np.array([O.fe_op("inv", f, a[i]) for i in range(2, 66)])).all()
+
+
+def test_point_ops(eng, oracle):
+    O = oracle
+    cv = eng.curve
+    n = 64
+    G, H = O.bp_gens(cv, n)
+    FR = O.fid(cv, True)
+    Q = H.copy()
+    Q[0] = G[0]                      # P + P
+    Q[1, 4:] = O.fe_op("sub", O.fid(cv, False), O.fe_from_int(O.fid(cv, False), 0), G[1, 4:])
+    Q[1, :4] = G[1, :4]              # P + (-P)
+    Q[2] = 0                         # P + identity
+    P = G.copy()
+    P[3] = 0                         # identity + Q
+    for op in (0, 1):
+        got = eng.debug_point_op(op, P, Q)
+        exp = np.array([O.point_add(cv, P[i], Q[i]) for i in range(n)])
+        assert (got == exp).all()
+    assert not got[1].any()
+    got = eng.debug_point_op(2, P, Q)
+    assert (got == np.array([O.point_add(cv, P[i], P[i]) for i in range(n)])).all()
+    k = O.fe_rand(FR, bytes([5]) * 32, n)
+    r = O.modulus(FR)
+    kc = np.array([O.int_to_limbs(O.fe_to_int(FR, x)) for x in k])
+    kc[0] = 0
+    kc[1] = O.int_to_limbs(r - 1)
+    kc[2] = O.int_to_limbs(1)
+    got = eng.debug_point_op(3, G, Q, kc)
+    exp = np.array([O.scalar_mul(cv, G[i], O.fe_from_int(FR, O.limbs_to_int(kc[i]))) for i in range(n)])
+    assert (got == exp).all()
+
+
+def _rand_scalars(O, cv, n, seed):
+    return O.fe_rand(O.fid(cv, True), bytes([seed]) * 32, n)
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 1000])
+def test_msm_small(eng, oracle, n):
+    O, cv = oracle, eng.curve
+    G, H = O.bp_gens(cv, max(n, 2))
+    bases = np.concatenate([G, H])[:n]
+    sc = _rand_scalars(O, cv, n, 2)
+    assert (eng.msm(bases, sc) == O.msm(cv, bases, sc)).all()
+
+
+def test_msm_edge_cases(eng, oracle):
+    O, cv = oracle, eng.curve
+    FR = O.fid(cv, True)
+    n = 512
+    G, H = O.bp_gens(cv, n)
+    r = O.modulus(FR)
+    zero, one, rm1 = O.fe_from_int(FR, 0), O.fe_from_int(FR, 1), O.fe_from_int(FR, r - 1)
+    # all-zero scalars -> identity
+    assert not eng.msm(G, np.tile(zero, (n, 1))).any()
+    # scalar = 1 everywhere: plain sum (one giant bucket per window: the skew path)
+    ones = np.tile(one, (n, 1))
+    assert (eng.msm(G, ones) == O.msm(cv, G, ones)).all()
+    # scalar = r - 1 everywhere
+    m1 = np.tile(rm1, (n, 1))
+    assert (eng.msm(G, m1) == O.msm(cv, G, m1)).all()
+    # duplicated bases, identity bases, P and -P with equal scalars (cancellation inside a bucket)
+    sc = _rand_scalars(O, cv, n, 3)
+    B = G.copy()
+    B[1] = B[0]
+    B[5] = 0
+    B[7, :4] = B[6, :4]
+    B[7, 4:] = O.fe_op("sub", O.fid(cv, False), O.fe_from_int(O.fid(cv, False), 0), B[6, 4:])
+    sc[7] = sc[6]
+    sc[1] = sc[0]
+    assert (eng.msm(B, sc) == O.msm(cv, B, sc)).all()
+    # all bases equal and all scalars equal (every add in a bucket is a doubling)
+    B2 = np.tile(G[3], (64, 1))
+    s2 = np.tile(sc[9], (64, 1))
+    assert (eng.msm(B2, s2) == O.msm(cv, B2, s2)).all()
+    # canonical-integer scalars flag
+    can = np.array([O.int_to_limbs(O.fe_to_int(FR, x)) for x in sc])
+    assert (eng.msm(G, can, canonical=True) == O.msm(cv, G, sc)).all()
+    # small 0/1 witness-like scalars
+    bits = np.array([O.fe_from_int(FR, (i * 7 + 3) % 2) for i in range(n)])
+    assert (eng.msm(H, bits) == O.msm(cv, H, bits)).all()
+    with pytest.raises(ValueError):
+        eng.msm(G[:4], sc[:3])
+
+
+def test_msm_cfg2_2pow16(eng, oracle):
+    """BASELINE.json configs[1]: 2^16-term MSM, bases = BulletproofGens(2^15) G||H, scalars from ChaCha20 seed [2;32]"""
+    O, cv = oracle, eng.curve
+    n = 1 << 16
+    G, H = O.bp_gens(cv, n // 2)
+    bases = np.concatenate([G, H])
+    sc = _rand_scalars(O, cv, n, 2)
+    got = eng.msm(bases, sc)
+    assert (got == O.msm(cv, bases, sc)).all()
+    # device-resident path + linearity: msm(b, s) + msm(b, s') == msm(b, s + s')
+    db, ds = eng.upload_points(bases), eng.upload_scalars(sc)
+    assert (eng.msm_dev(db, ds, n) == got).all()
+    db.free()
+    ds.free()
