@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py — measures the MSM / inner-product hot path on MI355X and prints ONE JSON line.
+
+  python bench.py --gpus N --steps K --warmup W [--workload msm|prove]
+
+A "step" is one pass of the hot path over one batch of synthetic, HBM-resident input.  For N > 1 the
+driver launches one rank per GPU with torch.distributed.run; units are sharded across ranks (weak
+scaling), the only exchange is the all-gather of one partial point per rank.
+
+Only the `cpu_baseline` leg touches oracle/ (the CPU restatement), as the timed CPU reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def dist_setup(n_gpus):
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def barrier(world):
+    import torch
+
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def synth_msm_inputs(eng, n, rank):
+    """cfg2 inputs without the (slow, sequential) generator derivation: bases = k_i * G for a seeded k_i
+    computed ON THE GPU by the engine's own scalar-mul kernel; scalars = seeded 256-bit values < r."""
+    import ark_bulletproofs_amd as A  # noqa: F401
+
+    rng = np.random.default_rng(1234 + rank)
+    gen = {0: (53718550993811904772965658690407829053653678808745171666022356150019200052646,
+               28941648020349172432234515805717979317553499307621291159490218670604692907903,
+               0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141),
+           1: (2, 19711758720854384559191066596451394956860102304684364148268676039962145446511,
+               57896044618658097711785492504343953927116110621106131396339151912985063395361)}[eng.curve]
+    q = gen[2]
+    R = 1 << 256
+
+    def limbs(x):
+        return [(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+    g = np.array(limbs(gen[0] * R % q) + limbs(gen[1] * R % q), dtype=np.uint64)
+    ks = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    ks[:, 3] >>= np.uint64(2)  # < 2^253 < r for both curves: canonical scalars
+    bases = np.zeros((n, 8), dtype=np.uint64)
+    step = 1 << 14
+    for i in range(0, n, step):
+        m = min(step, n - i)
+        bases[i:i + m] = eng.debug_point_op(3, np.tile(g, (m, 1)), np.tile(g, (m, 1)), ks[i:i + m])
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] >>= np.uint64(2)  # treated as Montgomery words of some scalar < r
+    return bases, sc
+
+
+def run_msm(args, rank, world, local):
+    import torch
+
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import _lib
+
+    n = args.terms
+    eng = A.Engine(curve=args.curve, device=local)
+    bases, sc = synth_msm_inputs(eng, n, rank)
+    db, ds = eng.upload_points(bases), eng.upload_scalars(sc)
+    for _ in range(args.warmup):
+        eng.msm_dev(db, ds, n)
+    eng.set_profiling(True)
+    eng.reset_profiling()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        part = eng.msm_dev(db, ds, n)
+        if world > 1:
+            import torch.distributed as dist
+
+            t = torch.from_numpy(part.view(np.int64).copy()).cuda()
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)  # one 64-byte partial point per rank; summed by the caller
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    acc_ms, acc_n = eng.kernel_time(0)
+    tot_ms, tot_n = eng.kernel_time(1)
+    res = {
+        "metric": "msm_terms_per_sec", "value": n * world * args.steps / dt, "unit": "terms/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
+        "config": {"workload": "cfg2: 2^%d-term variable-base MSM, %s, inputs HBM-resident" % (int(np.log2(n)), ["secq256k1", "zorro"][args.curve]),
+                   "terms_per_gpu": n, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": "term-sharded x%d" % world},
+    }
+    if acc_n:
+        avg_s = acc_ms / acc_n * 1e-3
+        res["roofline"] = {"bound": "hbm", "kernel": "k_msm_accum", "achieved": n * 96 / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": n * 96 / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": acc_ms / acc_n,
+                           "msm_all_kernels_ms": tot_ms / max(tot_n, 1),
+                           "note": "integer-VALU-bound path: see DESIGN.md for the modmul/s model"}
+    if rank == 0 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_msm(args, bases, sc)
+    db.free()
+    ds.free()
+    eng.close()
+    return res
+
+
+def cpu_baseline_msm(args, bases, sc):
+    """CPU restatement of ark-ec's VariableBaseMSM (oracle/curve.hpp), 1 thread, same inputs (bounded sample)."""
+    from oracle import pyoracle as O
+
+    m = min(len(bases), 1 << 16)
+    _, secs = O.msm(args.curve, bases[:m], sc[:m], timed=True)
+    return {"value": m / secs, "unit": "terms/s", "cores": 1, "kind": "port",
+            "sample": "%d-term MSM (same bases/scalars), ark window schedule, single thread" % m}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="msm")
+    ap.add_argument("--terms", type=int, default=1 << 16)
+    ap.add_argument("--curve", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank, world, local = dist_setup(args.gpus)
+    res = run_msm(args, rank, world, local)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
