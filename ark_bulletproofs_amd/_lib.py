@@ -15,7 +15,7 @@ BP_OK, BP_E_ARG, BP_E_HIP, BP_E_NO_DEVICE, BP_E_VERIFICATION, BP_E_GENS_LENGTH, 
 EXPORTS = [
     "bp_last_error", "bp_device_count", "bp_ctx_create", "bp_ctx_destroy", "bp_ctx_sync",
     "bp_dev_alloc", "bp_dev_free", "bp_dev_upload", "bp_dev_download", "bp_points_import", "bp_points_export",
-    "bp_msm", "bp_msm_dev", "bp_ctx_set_profiling", "bp_ctx_kernel_time", "bp_ctx_reset_profiling",
+    "bp_msm", "bp_msm_dev", "bp_ipa_create", "bp_ctx_set_profiling", "bp_ctx_kernel_time", "bp_ctx_reset_profiling",
     "bp_debug_field_op", "bp_debug_point_op",
 ]
 

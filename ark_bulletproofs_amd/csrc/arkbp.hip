@@ -4,11 +4,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/arkbp.h"
 #include "host_math.hpp"
-#include "msm.cuh"
+#include "ipa.cuh"
 
 using namespace arkbp;
 using arkbp::host::A4;
@@ -58,6 +59,8 @@ struct bp_ctx {
     std::vector<hipEvent_t> event_pool;
     // MSM workspaces
     DevBuf canon, hist, lvl_off, totals, cursor, entries, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
+    // IPA workspaces (resident layouts)
+    DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q;
     u32* h_totals = nullptr;  // pinned
     u32* h_T = nullptr;       // pinned
     size_t h_T_cap = 0;
@@ -189,6 +192,104 @@ template <class C> static int msm_dev_entry(bp_ctx* ctx, const void* d_bases, co
     return BP_OK;
 }
 
+
+// ---- InnerProductProof::create orchestration (src/inner_product_proof.rs:37-239) ------------------------
+// All vectors are device-resident in the engine's layouts and are consumed (folded in place), like the
+// reference's by-value Vec arguments.  `challenge` is the Fiat-Shamir step (:132-137): it receives affine
+// L, R (ark layout) and returns u (ark Montgomery words).
+typedef std::function<int(const uint64_t* L_xy, const uint64_t* R_xy, uint64_t* u_out)> ChallengeFn;
+
+template <class F> static Words8 words_of(const F4& x) { Words8 w; memcpy(w.w, x.v, 32); return w; }
+
+template <class C>
+static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b, size_t n,
+                          const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4]) {
+    typedef host::Fld<typename C::Fr> S;
+    typedef host::Grp<C> G;
+    if (n == 0 || (n & (n - 1))) { g_err = "ipa_create: n must be a power of two (reference asserts, src/inner_product_proof.rs:66)"; return BP_E_ARG; }
+    hipStream_t st = ctx->stream;
+    BPCHK(ctx->ipa_sL.ensure((n + 1) * 32));
+    BPCHK(ctx->ipa_sR.ensure((n + 1) * 32));
+    BPCHK(ctx->ipa_part.ensure(((n / 2 + 255) / 256 + 1) * 64));
+    bool first = true;
+    size_t round = 0;
+    while (n != 1) {
+        n /= 2;
+        const u32 gb = (u32)((n + 255) / 256);
+        u32* sL = ctx->ipa_sL.as<u32>();
+        u32* sR = ctx->ipa_sR.as<u32>();
+        {
+            ScopedK tk(ctx, BP_K_IPA_SCALARS);
+            hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, d_Gf, d_Hf, first ? 1 : 0, (u32)n, sL, sR, ctx->ipa_part.as<u32>());
+            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8);
+        }
+        BaseSegs sg; memset(&sg, 0, sizeof sg);
+        sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n; sg.start[2] = (u32)(2 * n); sg.start[3] = (u32)(2 * n + 1);
+        sg.ptr[0] = d_G + n * 16; sg.ptr[1] = d_H; sg.ptr[2] = d_Q;
+        J4 Lj, Rj;
+        BPCHK(msm_run<C>(ctx, sg, sL, 2 * n + 1, 0, Lj));
+        sg.ptr[0] = d_G; sg.ptr[1] = d_H + n * 16;
+        BPCHK(msm_run<C>(ctx, sg, sR, 2 * n + 1, 0, Rj));
+        A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
+        uint64_t Lw[8], Rw[8], uw[4];
+        memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
+        memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
+        memcpy(L_out + 8 * round, Lw, 64); memcpy(R_out + 8 * round, Rw, 64);
+        int rc = challenge(Lw, Rw, uw);
+        if (rc) { g_err = "ipa_create: challenge callback failed"; return rc < 0 ? rc : BP_E_ARG; }
+        F4 u; memcpy(u.v, uw, 32);
+        F4 ui = S::inv(u);
+        {
+            ScopedK tk(ctx, BP_K_IPA_FOLD);
+            hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
+            hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, first ? 1 : 0, (u32)n, words_of<S>(u),
+                               words_of<S>(ui));
+        }
+        HIPCHK(hipGetLastError());
+        first = false;
+        round++;
+    }
+    // a[0], b[0] -> ark layout on the host
+    BPCHK(ctx->io_out.ensure(64));
+    hipLaunchKernelGGL(k_scalars_export<typename C::Fr>, dim3(1), dim3(64), 0, st, d_a, ctx->io_out.as<u32>(), 1u);
+    hipLaunchKernelGGL(k_scalars_export<typename C::Fr>, dim3(1), dim3(64), 0, st, d_b, ctx->io_out.as<u32>() + 8, 1u);
+    uint64_t ab[8];
+    HIPCHK(hipMemcpyAsync(ab, ctx->io_out.p, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    memcpy(a_out, ab, 32); memcpy(b_out, ab + 4, 32);
+    if (ctx->profiling) collect_timers(ctx);
+    return BP_OK;
+}
+
+template <class C>
+static int ipa_create_host_entry(bp_ctx* ctx, const uint64_t* Q, const uint64_t* Gf, const uint64_t* Hf, const uint64_t* Gv, const uint64_t* Hv,
+                                 const uint64_t* a, const uint64_t* b, size_t n, const ChallengeFn& fn, uint64_t* L_out, uint64_t* R_out,
+                                 uint64_t* a_out, uint64_t* b_out) {
+    typedef typename C::Fr Fr;
+    hipStream_t st = ctx->stream;
+    BPCHK(ctx->ipa_G.ensure(n * 64)); BPCHK(ctx->ipa_H.ensure(n * 64));
+    BPCHK(ctx->ipa_a.ensure(n * 32)); BPCHK(ctx->ipa_b.ensure(n * 32));
+    BPCHK(ctx->ipa_Gf.ensure(n * 32)); BPCHK(ctx->ipa_Hf.ensure(n * 32));
+    BPCHK(ctx->ipa_Q.ensure(64));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_G.p, Gv, n * 64, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_H.p, Hv, n * 64, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_Q.p, Q, 64, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_a.p, a, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_b.p, b, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_Gf.p, Gf, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_Hf.p, Hf, n * 32, hipMemcpyHostToDevice, st));
+    BPCHK(bp_points_import(ctx, ctx->ipa_G.p, ctx->ipa_G.p, n));
+    BPCHK(bp_points_import(ctx, ctx->ipa_H.p, ctx->ipa_H.p, n));
+    BPCHK(bp_points_import(ctx, ctx->ipa_Q.p, ctx->ipa_Q.p, 1));
+    const u32 gb = (u32)((n + 255) / 256);
+    DevBuf* sc[] = {&ctx->ipa_a, &ctx->ipa_b, &ctx->ipa_Gf, &ctx->ipa_Hf};
+    for (auto s : sc) hipLaunchKernelGGL(k_scalars_import<Fr>, dim3(gb), dim3(256), 0, st, s->as<u32>(), s->as<u32>(), (u32)n);
+    HIPCHK(hipGetLastError());
+    return ipa_create_dev<C>(ctx, ctx->ipa_Q.as<u32>(), ctx->ipa_Gf.as<u32>(), ctx->ipa_Hf.as<u32>(), ctx->ipa_G.as<u32>(), ctx->ipa_H.as<u32>(),
+                             ctx->ipa_a.as<u32>(), ctx->ipa_b.as<u32>(), n, fn, L_out, R_out, a_out, b_out);
+}
+
 // ---- unit-test kernels -----------------------------------------------------------------------------
 template <class F> __global__ void k_dbg_field(int op, const u32* a, const u32* b, u32* out, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,7 +360,8 @@ void bp_ctx_destroy(bp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out};
+    DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
+                      &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q};
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
@@ -330,6 +432,19 @@ int bp_msm(bp_ctx* c, const uint64_t* bases_xy, const uint64_t* scalars, size_t 
     HIPCHK(hipMemcpyAsync(c->io_scal.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     BPCHK(bp_points_import(c, c->io_pts.p, c->io_pts.p, n));
     return bp_msm_dev(c, c->io_pts.p, c->io_scal.p, n, canonical, out_xy);
+}
+
+
+int bp_ipa_create(bp_ctx* c, const uint64_t Q_xy[8], const uint64_t* G_factors, const uint64_t* H_factors, const uint64_t* G_xy, const uint64_t* H_xy,
+                  const uint64_t* a, const uint64_t* b, size_t n, bp_challenge_cb cb, void* user, uint64_t* L_out_xy, uint64_t* R_out_xy, uint64_t a_out[4],
+                  uint64_t b_out[4]) {
+    if (!c || !Q_xy || !G_factors || !H_factors || !G_xy || !H_xy || !a || !b || !cb || !a_out || !b_out || (n > 1 && (!L_out_xy || !R_out_xy))) {
+        g_err = "bp_ipa_create: bad argument"; return BP_E_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    ChallengeFn fn = [cb, user](const uint64_t* L, const uint64_t* R, uint64_t* u) { return cb(user, L, R, u); };
+    return c->curve == 0 ? ipa_create_host_entry<Secq>(c, Q_xy, G_factors, H_factors, G_xy, H_xy, a, b, n, fn, L_out_xy, R_out_xy, a_out, b_out)
+                         : ipa_create_host_entry<Zorro>(c, Q_xy, G_factors, H_factors, G_xy, H_xy, a, b, n, fn, L_out_xy, R_out_xy, a_out, b_out);
 }
 
 int bp_ctx_set_profiling(bp_ctx* c, int enabled) { if (!c) return BP_E_ARG; c->profiling = enabled != 0; return BP_OK; }

@@ -1,0 +1,193 @@
+// Inner-product-argument round kernels for gfx950 — the device side of
+// `InnerProductProof::create` (/root/reference/src/inner_product_proof.rs:37-239).
+//
+// All four vectors stay resident in HBM for the whole recursion (the reference re-collects fresh Vecs
+// for every msm call, :86-122,:174-200); per round the host sees only L, R (2 points down) and
+// returns u, u^-1 (2 scalars up) — the Fiat-Shamir barrier of :132-137.
+//
+//   k_ipa_scalars   one lane per i < n: the 2n MSM scalars of L and R (:92-102,:112-122,:180-185,
+//                   :195-200; round 1 folds G_factors/H_factors in) written as canonical integers,
+//                   plus the two inner products c_L = <a_L,b_R>, c_R = <a_R,b_L> (:83-84,:171-172)
+//                   as per-workgroup partial sums (LDS tree)
+//   k_ipa_ip_finish one workgroup: sums the partials, appends c_L / c_R as scalar 2n
+//   k_ipa_fold_ab   a_L <- a_L*u + u^-1*a_R, b_L <- b_L*u^-1 + u*b_R  (:140-141,:217-218)
+//   k_ipa_fold_pts  G_L[i] <- s1*G_L[i] + s2*G_R[i], H_L[i] <- t1*H_L[i] + t2*H_R[i] (:143-155,:219-224)
+//                   as a joint (Shamir) double-and-add per lane, normalised back to affine in-lane.
+//                   The reference does this with a 2-term Pippenger msm + one inversion PER ELEMENT and
+//                   it is ~95% of its prove time.
+// Storage: scalars and points are in the engine's resident layout (packed radix-2^29 Montgomery form).
+#pragma once
+#include "msm.cuh"
+
+namespace arkbp {
+
+template <class F> __device__ __forceinline__ Fe load_fe_dev(const u32* p) {
+    u32 w[8];
+    load_words8(w, p);
+    return fe_unpack(w);
+}
+template <class F> __device__ __forceinline__ void store_fe_dev(u32* p, const Fe& a) {  // any L = 1, V < 32 value
+    u32 w[8];
+    fe_pack(w, fe_canon<F>(a));
+    store_words8(p, w);
+}
+template <class F> __device__ __forceinline__ void store_fe_canon(u32* p, const Fe& a) {
+    u32 w[8];
+    fe_store_canon<F>(w, a);
+    store_words8(p, w);
+}
+// lazy sum kept at L = 1, V <= 2
+template <class F> __device__ __forceinline__ Fe fe_addr(const Fe& a, const Fe& b) { return fe_wred<F>(fe_norm(fe_add(a, b))); }
+
+// workgroup tree-sum of one field element per lane (256 lanes); result valid in lane 0
+template <class F> __device__ __forceinline__ Fe block_sum_fe(Fe v, u32* sh /* 9*256 words */) {
+    const u32 tid = threadIdx.x;
+    for (u32 stride = 128; stride >= 1; stride >>= 1) {
+        if (tid >= stride && tid < 2 * stride) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) sh[i * 256 + tid] = v.l[i];
+        }
+        __syncthreads();
+        if (tid < stride) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 9; i++) o.l[i] = sh[i * 256 + tid + stride];
+            v = fe_addr<F>(v, o);
+        }
+        __syncthreads();
+    }
+    return v;
+}
+
+// ark-layout scalars (Montgomery R = 2^256) -> resident layout, and back
+template <class F> __global__ void k_scalars_import(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    load_words8(w, in + (size_t)i * 8);
+    store_fe_dev<F>(out + (size_t)i * 8, fe_load_ark<F>(w));
+}
+template <class F> __global__ void k_scalars_export(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    fe_store_ark<F>(w, load_fe_dev<F>(in + (size_t)i * 8));
+    store_words8(out + (size_t)i * 8, w);
+}
+
+// n = half length.  sL/sR: (2n+1) x 8 words each (canonical integers).  partials: gridDim.x x 2 x 8 words.
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ Gf, const u32* __restrict__ Hf, int first, u32 n,
+              u32* __restrict__ sL, u32* __restrict__ sR, u32* __restrict__ partials) {
+    typedef typename C::Fr F;
+    __shared__ u32 sh[9 * 256];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fe pl = fe_zero<F>(), pr = fe_zero<F>();
+    if (i < n) {
+        Fe aL = load_fe_dev<F>(a + (size_t)i * 8), aR = load_fe_dev<F>(a + (size_t)(n + i) * 8);
+        Fe bL = load_fe_dev<F>(b + (size_t)i * 8), bR = load_fe_dev<F>(b + (size_t)(n + i) * 8);
+        pl = fe_mul<F>(aL, bR);
+        pr = fe_mul<F>(aR, bL);
+        Fe xl = aL, yl = bR, xr = aR, yr = bL;
+        if (first) {
+            xl = fe_mul<F>(aL, load_fe_dev<F>(Gf + (size_t)(n + i) * 8));
+            yl = fe_mul<F>(bR, load_fe_dev<F>(Hf + (size_t)i * 8));
+            xr = fe_mul<F>(aR, load_fe_dev<F>(Gf + (size_t)i * 8));
+            yr = fe_mul<F>(bL, load_fe_dev<F>(Hf + (size_t)(n + i) * 8));
+        }
+        store_fe_canon<F>(sL + (size_t)i * 8, xl);
+        store_fe_canon<F>(sL + (size_t)(n + i) * 8, yl);
+        store_fe_canon<F>(sR + (size_t)i * 8, xr);
+        store_fe_canon<F>(sR + (size_t)(n + i) * 8, yr);
+    }
+    pl = block_sum_fe<F>(fe_wred<F>(pl), sh);
+    pr = block_sum_fe<F>(fe_wred<F>(pr), sh);
+    if (threadIdx.x == 0) {
+        store_fe_dev<F>(partials + (size_t)blockIdx.x * 16, pl);
+        store_fe_dev<F>(partials + (size_t)blockIdx.x * 16 + 8, pr);
+    }
+}
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_ip_finish(const u32* __restrict__ partials, u32 nparts, u32* __restrict__ outL, u32* __restrict__ outR) {
+    typedef typename C::Fr F;
+    __shared__ u32 sh[9 * 256];
+    Fe pl = fe_zero<F>(), pr = fe_zero<F>();
+    for (u32 j = threadIdx.x; j < nparts; j += 256) {
+        pl = fe_addr<F>(pl, load_fe_dev<F>(partials + (size_t)j * 16));
+        pr = fe_addr<F>(pr, load_fe_dev<F>(partials + (size_t)j * 16 + 8));
+    }
+    pl = block_sum_fe<F>(pl, sh);
+    pr = block_sum_fe<F>(pr, sh);
+    if (threadIdx.x == 0) {
+        store_fe_canon<F>(outL, pl);
+        store_fe_canon<F>(outR, pr);
+    }
+}
+
+struct Words8 {
+    u32 w[8];
+};
+
+// u, u_inv: ark Montgomery words
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_fold_ab(u32* __restrict__ a, u32* __restrict__ b, u32 n, Words8 uw, Words8 uiw) {
+    typedef typename C::Fr F;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fe u = fe_load_ark<F>(uw.w), ui = fe_load_ark<F>(uiw.w);
+    Fe aL = load_fe_dev<F>(a + (size_t)i * 8), aR = load_fe_dev<F>(a + (size_t)(n + i) * 8);
+    Fe bL = load_fe_dev<F>(b + (size_t)i * 8), bR = load_fe_dev<F>(b + (size_t)(n + i) * 8);
+    store_fe_dev<F>(a + (size_t)i * 8, fe_norm(fe_add(fe_mul<F>(aL, u), fe_mul<F>(ui, aR))));
+    store_fe_dev<F>(b + (size_t)i * 8, fe_norm(fe_add(fe_mul<F>(bL, ui), fe_mul<F>(u, bR))));
+}
+
+// joint double-and-add: s1*P1 + s2*P2 with canonical 256-bit s1, s2 (lane-private or wave-uniform)
+template <class C> __device__ __forceinline__ Jac shamir2(const Aff& P1, const Aff& P2, const u32 s1[8], const u32 s2[8]) {
+    const Jac T3 = jac_madd<C>(jac_from_aff<C>(P1), P2);
+    Jac acc = jac_inf<C>();
+#pragma unroll 1
+    for (int wd = 7; wd >= 0; wd--) {
+        const u32 e1 = s1[wd], e2 = s2[wd];
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; bit--) {
+            acc = jac_dbl<C>(acc);
+            const u32 sel = ((e1 >> bit) & 1) | (((e2 >> bit) & 1) << 1);
+            if (sel == 1) acc = jac_madd<C>(acc, P1);
+            else if (sel == 2) acc = jac_madd<C>(acc, P2);
+            else if (sel == 3) acc = jac_add<C>(acc, T3);
+        }
+    }
+    return acc;
+}
+
+// One lane per output point: lanes [0,n) fold G, lanes [n,2n) fold H.  first != 0: per-element factors.
+// u, u_inv ark Montgomery words.  In place: lane i reads elements i and n+i of its vector, writes i.
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_fold_pts(u32* __restrict__ G, u32* __restrict__ H, const u32* __restrict__ Gf, const u32* __restrict__ Hf, int first, u32 n, Words8 uw,
+               Words8 uiw) {
+    typedef typename C::Fr F;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const bool isH = t >= n;
+    const u32 i = isH ? t - n : t;
+    u32* V = isH ? H : G;
+    const u32* Vf = isH ? Hf : Gf;
+    // G: (u^-1 * Gf[i], u * Gf[n+i])      H: (u * Hf[i], u^-1 * Hf[n+i])
+    Fe c1 = fe_load_ark<F>(isH ? uw.w : uiw.w), c2 = fe_load_ark<F>(isH ? uiw.w : uw.w);
+    if (first) {
+        c1 = fe_mul<F>(c1, load_fe_dev<F>(Vf + (size_t)i * 8));
+        c2 = fe_mul<F>(c2, load_fe_dev<F>(Vf + (size_t)(n + i) * 8));
+    }
+    u32 s1[8], s2[8];
+    fe_store_canon<F>(s1, c1);
+    fe_store_canon<F>(s2, c2);
+    const Aff P1 = load_aff_dev(V + (size_t)i * 16), P2 = load_aff_dev(V + (size_t)(n + i) * 16);
+    const Jac r = shamir2<C>(P1, P2, s1, s2);
+    const Aff o = jac_to_aff<C>(r);
+    u32 w[16];
+    aff_store_dev(w, o);
+    store_words8(V + (size_t)i * 16, w);
+    store_words8(V + (size_t)i * 16 + 8, w + 8);
+}
+
+}  // namespace arkbp

@@ -110,3 +110,43 @@ class Engine:
         out = np.zeros_like(p)
         check(lib().bp_debug_point_op(self.ctx, op, ptr(p), ptr(q), ptr(k), ptr(out), C.c_size_t(len(p))), "bp_debug_point_op")
         return out
+
+
+# ---- InnerProductProof::create ---------------------------------------------------------------------
+_CHALLENGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+
+
+def _ipa_create(self, Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec, challenge):
+    """challenge(L_xy, R_xy) -> u (4 x u64 Montgomery words): the caller's transcript step
+    (append_point L, R; challenge_scalar u — src/inner_product_proof.rs:132-135)."""
+    G, H = u64arr(G_vec, 8), u64arr(H_vec, 8)
+    n = len(G)
+    arrs = [u64arr(Q, 8)] + [u64arr(x, 4) for x in (G_factors, H_factors)] + [G, H] + [u64arr(x, 4) for x in (a_vec, b_vec)]
+    for x in arrs[1:]:
+        if len(x) != n:
+            raise ValueError("ipa_create: vector lengths differ")  # the reference asserts
+    lg = max(n.bit_length() - 1, 0)
+    L = np.zeros((max(lg, 1), 8), dtype=np.uint64)
+    R = np.zeros((max(lg, 1), 8), dtype=np.uint64)
+    ao, bo = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    err = []
+
+    def cb(_user, Lp, Rp, up):
+        try:
+            u = challenge(np.array(Lp[:8], dtype=np.uint64), np.array(Rp[:8], dtype=np.uint64))
+            for i in range(4):
+                up[i] = int(u[i])
+            return 0
+        except Exception as e:  # never unwind through C
+            err.append(e)
+            return 1
+
+    cfn = _CHALLENGE_CB(cb)
+    rc = lib().bp_ipa_create(self.ctx, *[ptr(x) for x in arrs], C.c_size_t(n), cfn, None, ptr(L), ptr(R), ptr(ao), ptr(bo))
+    if err:
+        raise err[0]
+    check(rc, "bp_ipa_create")
+    return L[:lg], R[:lg], ao, bo
+
+
+Engine.ipa_create = _ipa_create

@@ -64,9 +64,23 @@ int bp_msm(bp_ctx* ctx, const uint64_t* bases_xy, const uint64_t* scalars, size_
  * 32 B.  This is the call the timed region of bench.py makes. */
 int bp_msm_dev(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int scalars_canonical, uint64_t out_xy[8]);
 
+/* ---- InnerProductProof::create -------------------------------------------------------------------
+ * Replaces `InnerProductProof::create(transcript, &Q, &G_factors, &H_factors, G_vec, H_vec, a_vec, b_vec)`
+ * (src/inner_product_proof.rs:37-239).  Host buffers of length n (a power of two, as the reference
+ * asserts at :58-66).  The Merlin transcript stays with the caller: once per halving round the engine
+ * hands the callback the affine L, R it would append (`append_point(b"L"|b"R")`, :132-133) and the
+ * callback returns u = `challenge_scalar(b"u")` (:135); u^-1 is derived by the engine.  A non-zero
+ * return from the callback aborts the call.  Outputs: L_vec, R_vec (lg n points each), a, b. */
+typedef int (*bp_challenge_cb)(void* user, const uint64_t L_xy[8], const uint64_t R_xy[8], uint64_t u_out[4]);
+int bp_ipa_create(bp_ctx* ctx, const uint64_t Q_xy[8], const uint64_t* G_factors, const uint64_t* H_factors, const uint64_t* G_xy,
+                  const uint64_t* H_xy, const uint64_t* a, const uint64_t* b, size_t n, bp_challenge_cb cb, void* user, uint64_t* L_out_xy,
+                  uint64_t* R_out_xy, uint64_t a_out[4], uint64_t b_out[4]);
+
 /* ---- profiling: HIP-event time of the dominant kernel of the last call, on the ctx stream ---------- */
 #define BP_K_MSM_ACCUM 0   /* bucket accumulation (k_msm_accum) */
 #define BP_K_MSM_TOTAL 1   /* all MSM kernels of the call, first launch to last */
+#define BP_K_IPA_SCALARS 2 /* k_ipa_scalars + k_ipa_ip_finish of one round */
+#define BP_K_IPA_FOLD 3    /* k_ipa_fold_ab + k_ipa_fold_pts of one round */
 #define BP_K_COUNT 8
 int bp_ctx_set_profiling(bp_ctx* ctx, int enabled);
 /* accumulated milliseconds and launch count since the last reset */
