@@ -15,7 +15,9 @@ BP_OK, BP_E_ARG, BP_E_HIP, BP_E_NO_DEVICE, BP_E_VERIFICATION, BP_E_GENS_LENGTH, 
 EXPORTS = [
     "bp_last_error", "bp_device_count", "bp_ctx_create", "bp_ctx_destroy", "bp_ctx_sync",
     "bp_dev_alloc", "bp_dev_free", "bp_dev_upload", "bp_dev_download", "bp_points_import", "bp_points_export",
-    "bp_msm", "bp_msm_dev", "bp_ipa_create", "bp_ctx_set_profiling", "bp_ctx_kernel_time", "bp_ctx_reset_profiling",
+    "bp_msm", "bp_msm_dev", "bp_ipa_create", "bp_gens_derive", "bp_gens_upload", "bp_gens_download", "bp_pedersen_gens",
+    "bp_host_derive_generators", "bp_transcript_new", "bp_transcript_free", "bp_transcript_append_message", "bp_transcript_challenge_bytes",
+    "bp_transcript_append_point", "bp_transcript_challenge_scalar", "bp_host_sha3_512", "bp_r1cs_prove_scenario", "bp_ctx_set_profiling", "bp_ctx_kernel_time", "bp_ctx_reset_profiling",
     "bp_debug_field_op", "bp_debug_point_op",
 ]
 
@@ -37,6 +39,7 @@ def lib():
             )
         _lib = C.CDLL(LIB_PATH)
         _lib.bp_last_error.restype = C.c_char_p
+        _lib.bp_transcript_new.restype = C.c_void_p
     return _lib
 
 

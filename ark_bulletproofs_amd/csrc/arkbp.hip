@@ -8,8 +8,9 @@
 #include <string>
 #include <vector>
 #include "../../include/arkbp.h"
-#include "host_math.hpp"
-#include "ipa.cuh"
+#include <chrono>
+#include "host_proto.hpp"
+#include "r1cs.cuh"
 
 using namespace arkbp;
 using arkbp::host::A4;
@@ -61,6 +62,12 @@ struct bp_ctx {
     DevBuf canon, hist, lvl_off, totals, cursor, entries, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
     // IPA workspaces (resident layouts)
     DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q;
+    // generator tables (BulletproofGens party 0, PedersenGens), resident layout
+    DevBuf d_G, d_H, d_pc;
+    size_t gens_cap = 0;
+    A4 pc_B, pc_Bb;
+    // R1CS prover / verifier vectors (resident scalar layout)
+    DevBuf r_aL, r_aR, r_aO, r_sL, r_sR, r_wL, r_wR, r_wO, r_msmsc, r_ypow, r_part, r_small, r_g, r_h, r_chal, r_tail;
     u32* h_totals = nullptr;  // pinned
     u32* h_T = nullptr;       // pinned
     size_t h_T_cap = 0;
@@ -91,6 +98,8 @@ static void collect_timers(bp_ctx* c) {
         c->timers[k].pending.clear();
     }
 }
+
+extern "C" int bp_points_import(bp_ctx* c, const void* d_in, void* d_out, size_t n);
 
 // ---- MSM orchestration ---------------------------------------------------------------------------
 static MsmPlan msm_plan(size_t n, int bits) {
@@ -290,6 +299,8 @@ static int ipa_create_host_entry(bp_ctx* ctx, const uint64_t* Q, const uint64_t*
                              ctx->ipa_a.as<u32>(), ctx->ipa_b.as<u32>(), n, fn, L_out, R_out, a_out, b_out);
 }
 
+#include "r1cs_host.inc"
+
 // ---- unit-test kernels -----------------------------------------------------------------------------
 template <class F> __global__ void k_dbg_field(int op, const u32* a, const u32* b, u32* out, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -361,7 +372,9 @@ void bp_ctx_destroy(bp_ctx* c) {
     collect_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
-                      &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q};
+                      &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q,
+                      &c->d_G, &c->d_H, &c->d_pc, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail};
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
@@ -445,6 +458,85 @@ int bp_ipa_create(bp_ctx* c, const uint64_t Q_xy[8], const uint64_t* G_factors, 
     ChallengeFn fn = [cb, user](const uint64_t* L, const uint64_t* R, uint64_t* u) { return cb(user, L, R, u); };
     return c->curve == 0 ? ipa_create_host_entry<Secq>(c, Q_xy, G_factors, H_factors, G_xy, H_xy, a, b, n, fn, L_out_xy, R_out_xy, a_out, b_out)
                          : ipa_create_host_entry<Zorro>(c, Q_xy, G_factors, H_factors, G_xy, H_xy, a, b, n, fn, L_out_xy, R_out_xy, a_out, b_out);
+}
+
+// ---- generators -------------------------------------------------------------------------------------
+int bp_gens_derive(bp_ctx* c, size_t cap) {
+    if (!c || !cap) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? gens_derive<Secq>(c, cap) : gens_derive<Zorro>(c, cap);
+}
+int bp_gens_upload(bp_ctx* c, const uint64_t* G_xy, const uint64_t* H_xy, size_t cap) {
+    if (!c || !G_xy || !H_xy || !cap) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? gens_install<Secq>(c, G_xy, H_xy, cap) : gens_install<Zorro>(c, G_xy, H_xy, cap);
+}
+int bp_gens_download(bp_ctx* c, uint64_t* G_xy, uint64_t* H_xy, size_t n) {
+    if (!c || !G_xy || !H_xy || n > c->gens_cap) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    BPCHK(c->io_pts.ensure(n * 64));
+    for (int k = 0; k < 2; k++) {
+        BPCHK(bp_points_export(c, k ? c->d_H.p : c->d_G.p, c->io_pts.p, n));
+        HIPCHK(hipMemcpyAsync(k ? H_xy : G_xy, c->io_pts.p, n * 64, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return BP_OK;
+}
+int bp_pedersen_gens(int curve, uint64_t B_xy[8], uint64_t B_blinding_xy[8]) {
+    if (!B_xy || !B_blinding_xy) return BP_E_ARG;
+    A4 B, Bb;
+    if (curve == 0) { auto g = host::PedersenGens<Secq>::make_default(); B = g.B; Bb = g.B_blinding; }
+    else if (curve == 1) { auto g = host::PedersenGens<Zorro>::make_default(); B = g.B; Bb = g.B_blinding; }
+    else return BP_E_ARG;
+    memcpy(B_xy, B.x.v, 32); memcpy(B_xy + 4, B.y.v, 32); memcpy(B_blinding_xy, Bb.x.v, 32); memcpy(B_blinding_xy + 4, Bb.y.v, 32);
+    return BP_OK;
+}
+int bp_host_derive_generators(int curve, int which_H, uint32_t party, size_t count, uint64_t* out_xy) {
+    if (!out_xy) return BP_E_ARG;
+    std::vector<A4> v;
+    if (curve == 0) host::derive_generators<Secq>(v, which_H ? 'H' : 'G', party, count);
+    else if (curve == 1) host::derive_generators<Zorro>(v, which_H ? 'H' : 'G', party, count);
+    else return BP_E_ARG;
+    memcpy(out_xy, v.data(), count * 64);
+    return BP_OK;
+}
+
+// ---- host transcript (the product's own merlin restatement), exposed for CPU-side tests and for shims ----
+void* bp_transcript_new(const uint8_t* label, size_t n) { return new host::Transcript(label, n); }
+void bp_transcript_free(void* t) { delete (host::Transcript*)t; }
+void bp_transcript_append_message(void* t, const char* label, const uint8_t* m, size_t n) { ((host::Transcript*)t)->append_message(label, m, n); }
+void bp_transcript_challenge_bytes(void* t, const char* label, uint8_t* out, size_t n) { ((host::Transcript*)t)->challenge_bytes(label, out, n); }
+int bp_transcript_append_point(int curve, void* t, const char* label, const uint64_t xy[8]) {
+    A4 p; memcpy(p.x.v, xy, 32); memcpy(p.y.v, xy + 4, 32);
+    if (curve == 0) host::TP<Secq>::append_point(*(host::Transcript*)t, label, p);
+    else if (curve == 1) host::TP<Zorro>::append_point(*(host::Transcript*)t, label, p);
+    else return BP_E_ARG;
+    return BP_OK;
+}
+int bp_transcript_challenge_scalar(int curve, void* t, const char* label, uint64_t out[4]) {
+    F4 r;
+    if (curve == 0) r = host::TP<Secq>::challenge_scalar(*(host::Transcript*)t, label);
+    else if (curve == 1) r = host::TP<Zorro>::challenge_scalar(*(host::Transcript*)t, label);
+    else return BP_E_ARG;
+    memcpy(out, r.v, 32);
+    return BP_OK;
+}
+int bp_host_sha3_512(const uint8_t* m, size_t n, uint8_t out[64]) { host::sha3_512(out, m, n); return BP_OK; }
+
+// ---- R1CS prove (scenario-level driver) ---------------------------------------------------------------
+int bp_r1cs_prove_scenario(bp_ctx* c, int scenario, const uint64_t* params, const uint8_t seed[32], uint8_t* proof_out, size_t* proof_len,
+                           uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, double* timing) {
+    if (!c || !params || !seed || !proof_out || !proof_len || !commit_xy || !m_out || !publics || !npub) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<host::u8> bytes;
+    host::StatementIO io;
+    int rc = c->curve == 0 ? prove_scenario<Secq>(c, scenario, params, seed, bytes, io, timing) : prove_scenario<Zorro>(c, scenario, params, seed, bytes, io, timing);
+    if (rc) return rc;
+    if (bytes.size() > *proof_len || io.commitments.size() > m_cap || io.publics.size() > 8) { g_err = "prove: output buffer too small"; return BP_E_ARG; }
+    memcpy(proof_out, bytes.data(), bytes.size()); *proof_len = bytes.size();
+    memcpy(commit_xy, io.commitments.data(), io.commitments.size() * 64); *m_out = io.commitments.size();
+    memcpy(publics, io.publics.data(), io.publics.size() * 32); *npub = io.publics.size();
+    return BP_OK;
 }
 
 int bp_ctx_set_profiling(bp_ctx* c, int enabled) { if (!c) return BP_E_ARG; c->profiling = enabled != 0; return BP_OK; }

@@ -1,0 +1,537 @@
+// Host-side protocol layer of the PRODUCT (C++ mirror of the reference's Rust interface for the hot path):
+// Merlin transcript + TranscriptProtocol (src/transcript.rs:45-102), generator derivation
+// (src/generators.rs:47-121,174-221), the constraint-system recorder the prover/verifier need
+// (src/r1cs/prover.rs:96-268, verifier.rs:69-224, linear_combination.rs), proof wire codec
+// (src/r1cs/proof.rs:74-91).  These are sequential / O(1)-sized or run once per statement; every O(N)
+// vector operation of prove / verify runs in HIP kernels (r1cs.cuh, ipa.cuh, msm.cuh).
+// Byte-level behaviour follows SURVEY.md Appendix A (merlin 3.0, rand_chacha 0.3, sha3 0.10,
+// ark-serialize 0.4).  Independent of the test oracle.
+#pragma once
+#include <algorithm>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <utility>
+#include <vector>
+#include "../../include/arkbp.h"
+#include "host_math.hpp"
+
+namespace arkbp {
+namespace host {
+
+// ---- Keccak-f[1600], 64-bit lanes, theta/rho-pi/chi/iota per round -----------------------------------
+static inline u64 rol(u64 x, unsigned s) { return (x << s) | (x >> (64 - s)); }
+static inline void keccakf(u64 s[25]) {
+    static const u64 rc[24] = {0x1ULL, 0x8082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x808bULL, 0x80000001ULL,
+                               0x8000000080008081ULL, 0x8000000000008009ULL, 0x8aULL, 0x88ULL, 0x80008009ULL, 0x8000000aULL,
+                               0x8000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                               0x8000000000008002ULL, 0x8000000000000080ULL, 0x800aULL, 0x800000008000000aULL,
+                               0x8000000080008081ULL, 0x8000000000008080ULL, 0x80000001ULL, 0x8000000080008008ULL};
+    static const unsigned rot[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    static const unsigned pil[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    for (int r = 0; r < 24; r++) {
+        u64 bc[5];
+        for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
+        for (int i = 0; i < 5; i++) {
+            u64 t = bc[(i + 4) % 5] ^ rol(bc[(i + 1) % 5], 1);
+            for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
+        }
+        u64 t = s[1];
+        for (int i = 0; i < 24; i++) { unsigned j = pil[i]; u64 b = s[j]; s[j] = rol(t, rot[i]); t = b; }
+        for (int j = 0; j < 25; j += 5) {
+            u64 a0 = s[j], a1 = s[j + 1], a2 = s[j + 2], a3 = s[j + 3], a4 = s[j + 4];
+            s[j] = a0 ^ (~a1 & a2); s[j + 1] = a1 ^ (~a2 & a3); s[j + 2] = a2 ^ (~a3 & a4); s[j + 3] = a3 ^ (~a4 & a0); s[j + 4] = a4 ^ (~a0 & a1);
+        }
+        s[0] ^= rc[r];
+    }
+}
+static inline void sha3_512(u8 out[64], const u8* m, size_t n) {
+    u64 s[25] = {0};
+    u8* b = (u8*)s;
+    size_t pos = 0;
+    for (size_t i = 0; i < n; i++) { b[pos++] ^= m[i]; if (pos == 72) { keccakf(s); pos = 0; } }
+    b[pos] ^= 0x06; b[71] ^= 0x80;
+    keccakf(s);
+    memcpy(out, b, 64);
+}
+
+// ---- ChaCha20Rng (rand_chacha 0.3: 64-bit counter, stream 0, sequential u32 word stream) ------------------
+struct ChaChaRng {
+    u32 k[8]; u64 ctr; u32 blk[16]; int at;
+    explicit ChaChaRng(const u8 seed[32]) { memcpy(k, seed, 32); ctr = 0; at = 16; }
+    static inline u32 r(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+    void block() {
+        u32 in[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574, k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], (u32)ctr, (u32)(ctr >> 32), 0, 0};
+        u32 x[16]; memcpy(x, in, 64);
+        auto qr = [&](int a, int b, int c, int d) {
+            x[a] += x[b]; x[d] = r(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = r(x[b] ^ x[c], 12);
+            x[a] += x[b]; x[d] = r(x[d] ^ x[a], 8); x[c] += x[d]; x[b] = r(x[b] ^ x[c], 7);
+        };
+        for (int i = 0; i < 10; i++) { qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15); qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14); }
+        for (int i = 0; i < 16; i++) blk[i] = x[i] + in[i];
+        ctr++; at = 0;
+    }
+    u32 next_u32() { if (at == 16) block(); return blk[at++]; }
+    u64 next_u64() { u64 lo = next_u32(); return lo | ((u64)next_u32() << 32); }
+    void fill_bytes(u8* d, size_t n) { while (n) { u32 w = next_u32(); size_t c = n < 4 ? n : 4; memcpy(d, &w, c); d += c; n -= c; } }
+};
+
+// ---- STROBE-128 / merlin ----------------------------------------------------------------------------
+struct Strobe {
+    union { u64 w[25]; u8 b[200]; } st;
+    u8 pos, pos_begin, cur;
+    enum { RATE = 166, fI = 1, fA = 2, fC = 4, fM = 16, fK = 32 };
+    void init(const u8* label, size_t n) {
+        memset(&st, 0, sizeof st);
+        const u8 h[18] = {1, RATE + 2, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
+        memcpy(st.b, h, 18);
+        keccakf(st.w);
+        pos = pos_begin = cur = 0;
+        meta_ad(label, n, false);
+    }
+    inline void runf() { st.b[pos] ^= pos_begin; st.b[pos + 1] ^= 0x04; st.b[RATE + 1] ^= 0x80; keccakf(st.w); pos = 0; pos_begin = 0; }
+    inline void absorb(const u8* d, size_t n) { for (size_t i = 0; i < n; i++) { st.b[pos++] ^= d[i]; if (pos == RATE) runf(); } }
+    inline void overwrite(const u8* d, size_t n) { for (size_t i = 0; i < n; i++) { st.b[pos++] = d[i]; if (pos == RATE) runf(); } }
+    inline void squeeze(u8* d, size_t n) { for (size_t i = 0; i < n; i++) { d[i] = st.b[pos]; st.b[pos++] = 0; if (pos == RATE) runf(); } }
+    inline void begin(u8 flags, bool more) {
+        if (more) return;
+        u8 hdr[2] = {pos_begin, flags};
+        pos_begin = pos + 1; cur = flags;
+        absorb(hdr, 2);
+        if ((flags & (fC | fK)) && pos != 0) runf();
+    }
+    void meta_ad(const u8* d, size_t n, bool more) { begin(fM | fA, more); absorb(d, n); }
+    void ad(const u8* d, size_t n, bool more) { begin(fA, more); absorb(d, n); }
+    void prf(u8* d, size_t n, bool more) { begin(fI | fA | fC, more); squeeze(d, n); }
+    void key(const u8* d, size_t n, bool more) { begin(fA | fC, more); overwrite(d, n); }
+};
+
+struct Transcript {
+    Strobe s;
+    Transcript() {}
+    Transcript(const u8* label, size_t n) { s.init((const u8*)"Merlin v1.0", 11); append_message("dom-sep", label, n); }
+    explicit Transcript(const char* label) : Transcript((const u8*)label, strlen(label)) {}
+    void append_message(const char* label, const u8* m, size_t n) {
+        u32 len = (u32)n;
+        s.meta_ad((const u8*)label, strlen(label), false); s.meta_ad((const u8*)&len, 4, true); s.ad(m, n, false);
+    }
+    void append_message(const char* label, const char* m) { append_message(label, (const u8*)m, strlen(m)); }
+    void append_u64(const char* label, u64 x) { append_message(label, (const u8*)&x, 8); }
+    void challenge_bytes(const char* label, u8* d, size_t n) {
+        u32 len = (u32)n;
+        s.meta_ad((const u8*)label, strlen(label), false); s.meta_ad((const u8*)&len, 4, true); s.prf(d, n, false);
+    }
+};
+// merlin TranscriptRng as the prover uses it (src/r1cs/prover.rs:483-494)
+struct TranscriptRng {
+    Strobe s;
+    explicit TranscriptRng(const Transcript& t) : s(t.s) {}
+    void rekey(const char* label, const u8* w, size_t n) {
+        u32 len = (u32)n;
+        s.meta_ad((const u8*)label, strlen(label), false); s.meta_ad((const u8*)&len, 4, true); s.key(w, n, false);
+    }
+    template <class R> void finalize(R& ext) { u8 b[32]; ext.fill_bytes(b, 32); s.meta_ad((const u8*)"rng", 3, false); s.key(b, 32, false); }
+    inline u64 next_u64() { u32 len = 8; u64 x; s.meta_ad((const u8*)&len, 4, false); s.prf((u8*)&x, 8, false); return x; }
+    inline u32 next_u32() { u32 len = 4; u32 x; s.meta_ad((const u8*)&len, 4, false); s.prf((u8*)&x, 4, false); return x; }
+};
+
+// ark-ff Fp::rand: raw limbs (top limb masked to the modulus width) accepted iff < p; they ARE the Montgomery form
+template <class P, class R> static inline F4 rand_fe(R& rng) {
+    for (;;) {
+        F4 x;
+        for (int i = 0; i < 4; i++) x.v[i] = rng.next_u64();
+        if (P::BITS < 256) x.v[3] &= (~(u64)0) >> (256 - P::BITS);
+        if (!Fld<P>::geq_p(x.v)) return x;
+    }
+}
+// ark-ec Affine::rand (cofactor 1): x <- Fq::rand, greatest <- bool, retry until x is on the curve
+template <class C, class R> static inline A4 rand_point(R& rng) {
+    for (;;) {
+        F4 x = rand_fe<typename C::Fq>(rng);
+        bool greatest = ((int32_t)rng.next_u32()) < 0;
+        A4 p;
+        if (Grp<C>::from_x(p, x, greatest)) return p;
+    }
+}
+
+// ---- TranscriptProtocol (src/transcript.rs:45-102) -------------------------------------------------------
+template <class C> struct TP {
+    typedef Fld<typename C::Fr> S;
+    static void append_scalar(Transcript& t, const char* label, const F4& x) { u8 b[32]; S::to_bytes(b, x); t.append_message(label, b, 32); }
+    static void append_point(Transcript& t, const char* label, const A4& p) { u8 b[65]; Grp<C>::ser_uncompressed(b, p); t.append_message(label, b, 65); }
+    static bool validate_and_append_point(Transcript& t, const char* label, const A4& p) { if (p.is_inf()) return false; append_point(t, label, p); return true; }
+    static F4 challenge_scalar(Transcript& t, const char* label) {
+        u8 buf[32]; t.challenge_bytes(label, buf, 32);
+        ChaChaRng prng(buf);
+        return rand_fe<typename C::Fr>(prng);
+    }
+    static void innerproduct_domain_sep(Transcript& t, u64 n) { t.append_message("dom-sep", "ipp v1"); t.append_u64("n", n); }
+    static void r1cs_domain_sep(Transcript& t) { t.append_message("dom-sep", "r1cs v1"); }
+    static void r1cs_1phase_domain_sep(Transcript& t) { t.append_message("dom-sep", "r1cs-1phase"); }
+    static void r1cs_2phase_domain_sep(Transcript& t) { t.append_message("dom-sep", "r1cs-2phase"); }
+};
+
+// ---- generators ------------------------------------------------------------------------------------------
+template <class C> struct PedersenGens {
+    A4 B, B_blinding;
+    static PedersenGens make_default() {  // src/generators.rs:47-66
+        PedersenGens g; g.B = Grp<C>::generator();
+        u8 ser[65], h[64];
+        Grp<C>::ser_uncompressed(ser, g.B);
+        sha3_512(h, ser, 65);
+        ChaChaRng prng(h);
+        g.B_blinding = rand_point<C>(prng);
+        return g;
+    }
+    A4 commit(const F4& v, const F4& blind) const {  // src/generators.rs:39-44
+        return Grp<C>::to_aff(Grp<C>::add(Grp<C>::mul(B, v), Grp<C>::mul(B_blinding, blind)));
+    }
+};
+
+// GeneratorsChain (src/generators.rs:71-121) for label 'G'|'H' || LE32(party).  The ChaCha20 word stream is
+// consumed strictly in order, but the expensive part of each draw (a square root) does not feed back into
+// the stream position, so: (1) one thread walks the stream and records every (x, greatest) attempt,
+// (2) all threads test attempts in parallel, (3) successes are compacted in stream order.
+template <class C> static void derive_generators(std::vector<A4>& out, char which, u32 party, size_t count, unsigned nthreads = 0) {
+    u8 msg[20]; memcpy(msg, "GeneratorsChain", 15); msg[15] = (u8)which; memcpy(msg + 16, &party, 4);
+    u8 h[64]; sha3_512(h, msg, 20);
+    ChaChaRng prng(h);
+    if (!nthreads) nthreads = std::max(1u, std::thread::hardware_concurrency());
+    out.clear(); out.reserve(count);
+    struct Attempt { F4 x; bool greatest; };
+    while (out.size() < count) {
+        size_t want = (count - out.size()) * 2 + 64;
+        std::vector<Attempt> att(want);
+        for (auto& a : att) { a.x = rand_fe<typename C::Fq>(prng); a.greatest = ((int32_t)prng.next_u32()) < 0; }
+        std::vector<A4> pts(want); std::vector<u8> ok(want);
+        auto work = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) ok[i] = Grp<C>::from_x(pts[i], att[i].x, att[i].greatest) ? 1 : 0; };
+        if (nthreads <= 1 || want < 256) work(0, want);
+        else {
+            std::vector<std::thread> th;
+            size_t per = (want + nthreads - 1) / nthreads;
+            for (unsigned t = 0; t < nthreads; t++) { size_t lo = t * per, hi = std::min(want, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
+            for (auto& t : th) t.join();
+        }
+        size_t used = want;
+        for (size_t i = 0; i < want; i++) if (ok[i]) { out.push_back(pts[i]); if (out.size() == count) { used = i + 1; break; } }
+        if (out.size() == count && used < want) {
+            // the chain is only ever extended from a fresh stream (increase_capacity re-derives), so the
+            // over-read attempts past `used` are simply dropped
+        }
+    }
+}
+
+// ---- R1CS recording (src/r1cs/linear_combination.rs, constraint_system.rs) -----------------------------------
+enum VKind : u8 { VK_COMMITTED = 0, VK_LEFT = 1, VK_RIGHT = 2, VK_OUT = 3, VK_ONE = 4 };
+struct Var { VKind k; u32 i; };
+struct Term { Var v; F4 c; };
+typedef std::vector<Term> LinComb;
+
+enum { SC_SHUFFLE = 0, SC_RANGE = 1, SC_EXAMPLE = 2, SC_SQUARE_CHAIN = 3, SC_MULTI_RANGE = 4 };
+static inline const char* scenario_label(int sc) {
+    switch (sc) {
+        case SC_SHUFFLE: return "ShuffleBenchmark";
+        case SC_RANGE: return "RangeProofTest";
+        case SC_EXAMPLE: return "R1CSExampleGadget";
+        case SC_SQUARE_CHAIN: return "SquareChainBenchmark";
+        default: return "MultiRangeBenchmark";
+    }
+}
+
+// The recorder shared by prover and verifier: the verifier records the same constraints without
+// assignments.  Constraints are stored flat (CSR-like) because circuits reach 2^22 multipliers.
+template <class C> struct ConstraintSystem {
+    typedef Fld<typename C::Fr> S;
+    Transcript* tr = nullptr;
+    bool proving = false;
+    // flat constraint storage: constraint q owns terms [cs_off[q], cs_off[q+1])
+    std::vector<Term> cs_terms;
+    std::vector<size_t> cs_off{0};
+    size_t num_vars = 0;
+    bool has_pending = false; size_t pending = 0;
+    std::vector<std::function<int(ConstraintSystem&)>> deferred;
+    // prover secrets
+    std::vector<F4> v, v_blinding, a_L, a_R, a_O;
+    // verifier commitments
+    std::vector<A4> V;
+
+    F4 one() const { return S::one(); }
+    LinComb lc_var(Var x) const { return LinComb{Term{x, S::one()}}; }
+    LinComb lc_const(const F4& c) const { return LinComb{Term{Var{VK_ONE, 0}, c}}; }
+    static void lc_sub(LinComb& a, const LinComb& b) { for (auto& t : b) a.push_back(Term{t.v, S::neg(t.c)}); }
+    static void lc_add(LinComb& a, const LinComb& b) { a.insert(a.end(), b.begin(), b.end()); }
+
+    F4 eval(const LinComb& lc) const {  // prover.rs:399-414
+        F4 acc = S::zero();
+        for (auto& t : lc) {
+            F4 val;
+            switch (t.v.k) {
+                case VK_LEFT: val = a_L[t.v.i]; break;
+                case VK_RIGHT: val = a_R[t.v.i]; break;
+                case VK_OUT: val = a_O[t.v.i]; break;
+                case VK_COMMITTED: val = v[t.v.i]; break;
+                default: val = S::one(); break;
+            }
+            acc = S::add(acc, S::mul(t.c, val));
+        }
+        return acc;
+    }
+    void constrain(const LinComb& lc) { cs_terms.insert(cs_terms.end(), lc.begin(), lc.end()); cs_off.push_back(cs_terms.size()); }
+    // multiply (prover.rs:103-133 / verifier.rs:74-98)
+    void multiply(LinComb left, LinComb right, Var out[3]) {
+        u32 i = (u32)num_vars++;
+        if (proving) { F4 l = eval(left), r = eval(right); a_L.push_back(l); a_R.push_back(r); a_O.push_back(S::mul(l, r)); }
+        out[0] = Var{VK_LEFT, i}; out[1] = Var{VK_RIGHT, i}; out[2] = Var{VK_OUT, i};
+        F4 m1 = S::neg(S::one());
+        left.push_back(Term{out[0], m1}); right.push_back(Term{out[1], m1});
+        constrain(left); constrain(right);
+    }
+    // allocate (prover.rs:135-157 / verifier.rs:100-116)
+    int allocate(const F4* assignment, Var& out) {
+        if (proving && !assignment) return BP_E_MISSING;
+        if (!has_pending) {
+            u32 i = (u32)num_vars++;
+            has_pending = true; pending = i;
+            if (proving) { a_L.push_back(*assignment); a_R.push_back(S::zero()); a_O.push_back(S::zero()); }
+            out = Var{VK_LEFT, i};
+        } else {
+            has_pending = false;
+            if (proving) { a_R[pending] = *assignment; a_O[pending] = S::mul(a_L[pending], a_R[pending]); }
+            out = Var{VK_RIGHT, (u32)pending};
+        }
+        return BP_OK;
+    }
+    // allocate_multiplier (prover.rs:159-183 / verifier.rs:118-138)
+    int allocate_multiplier(const F4* l, const F4* r, Var out[3]) {
+        if (proving && (!l || !r)) return BP_E_MISSING;
+        u32 i = (u32)num_vars++;
+        if (proving) { a_L.push_back(*l); a_R.push_back(*r); a_O.push_back(S::mul(*l, *r)); }
+        out[0] = Var{VK_LEFT, i}; out[1] = Var{VK_RIGHT, i}; out[2] = Var{VK_OUT, i};
+        return BP_OK;
+    }
+    void specify_randomized_constraints(std::function<int(ConstraintSystem&)> cb) { deferred.push_back(std::move(cb)); }
+    F4 challenge_scalar(const char* label) { return TP<C>::challenge_scalar(*tr, label); }
+    // create_randomized_constraints (prover.rs:418-441 / verifier.rs:353-376)
+    int run_randomized() {
+        has_pending = false;
+        if (deferred.empty()) { TP<C>::r1cs_1phase_domain_sep(*tr); return BP_OK; }
+        TP<C>::r1cs_2phase_domain_sep(*tr);
+        std::vector<std::function<int(ConstraintSystem&)>> cbs; cbs.swap(deferred);
+        for (auto& cb : cbs) { int rc = cb(*this); if (rc) return rc; }
+        return BP_OK;
+    }
+    size_t num_constraints() const { return cs_off.size() - 1; }
+    // flattened_constraints (prover.rs:354-397 / verifier.rs:304-349): w* = sum_q z^(q+1) * W*[q, .]
+    void flatten(const F4& z, std::vector<F4>& wL, std::vector<F4>& wR, std::vector<F4>& wO, std::vector<F4>& wV, F4& wc, size_t m) const {
+        size_t n = num_vars;
+        wL.assign(n, S::zero()); wR.assign(n, S::zero()); wO.assign(n, S::zero()); wV.assign(m, S::zero()); wc = S::zero();
+        F4 ez = z;
+        for (size_t q = 0; q + 1 < cs_off.size(); q++) {
+            for (size_t k = cs_off[q]; k < cs_off[q + 1]; k++) {
+                const Term& t = cs_terms[k];
+                F4 p = S::mul(ez, t.c);
+                switch (t.v.k) {
+                    case VK_LEFT: wL[t.v.i] = S::add(wL[t.v.i], p); break;
+                    case VK_RIGHT: wR[t.v.i] = S::add(wR[t.v.i], p); break;
+                    case VK_OUT: wO[t.v.i] = S::add(wO[t.v.i], p); break;
+                    case VK_COMMITTED: wV[t.v.i] = S::sub(wV[t.v.i], p); break;
+                    default: wc = S::sub(wc, p); break;
+                }
+            }
+            ez = S::mul(ez, z);
+        }
+    }
+};
+
+// ---- gadgets (benches/r1cs_secq256k1.rs:34-76; tests/r1cs_secq256k1.rs:216-228, 361-393) -----------------------
+template <class C> static int shuffle_gadget(ConstraintSystem<C>& cs, std::vector<Var> x, std::vector<Var> y) {
+    typedef ConstraintSystem<C> CS;
+    size_t k = x.size();
+    if (k != y.size()) return BP_E_ARG;
+    if (k == 1) { LinComb lc = cs.lc_var(y[0]); CS::lc_sub(lc, cs.lc_var(x[0])); cs.constrain(lc); return BP_OK; }
+    cs.specify_randomized_constraints([x, y, k](CS& cs) -> int {
+        F4 z = cs.challenge_scalar("shuffle challenge");
+        auto mz = [&](Var v) { LinComb l = cs.lc_var(v); CS::lc_sub(l, cs.lc_const(z)); return l; };
+        Var o[3];
+        cs.multiply(mz(x[k - 1]), mz(x[k - 2]), o);
+        Var prev = o[2];
+        for (size_t i = k - 2; i-- > 0;) { cs.multiply(cs.lc_var(prev), mz(x[i]), o); prev = o[2]; }
+        Var fx = prev;
+        cs.multiply(mz(y[k - 1]), mz(y[k - 2]), o);
+        prev = o[2];
+        for (size_t i = k - 2; i-- > 0;) { cs.multiply(cs.lc_var(prev), mz(y[i]), o); prev = o[2]; }
+        LinComb lc = cs.lc_var(fx); CS::lc_sub(lc, cs.lc_var(prev)); cs.constrain(lc);
+        return BP_OK;
+    });
+    return BP_OK;
+}
+template <class C> static int range_gadget(ConstraintSystem<C>& cs, LinComb v, const u64* assignment, size_t nbits) {
+    typedef ConstraintSystem<C> CS; typedef Fld<typename C::Fr> S;
+    F4 exp2 = S::one();
+    for (size_t i = 0; i < nbits; i++) {
+        Var abo[3]; int rc;
+        if (assignment) { u64 bit = (*assignment >> i) & 1; F4 l = S::from_u64(1 - bit), r = S::from_u64(bit); rc = cs.allocate_multiplier(&l, &r, abo); }
+        else rc = cs.allocate_multiplier(nullptr, nullptr, abo);
+        if (rc) return rc;
+        cs.constrain(cs.lc_var(abo[2]));
+        LinComb ab = cs.lc_var(abo[0]); CS::lc_add(ab, cs.lc_var(abo[1])); CS::lc_sub(ab, cs.lc_const(S::one())); cs.constrain(ab);
+        v.push_back(Term{abo[1], S::neg(exp2)});
+        exp2 = S::dbl(exp2);
+    }
+    cs.constrain(v);
+    return BP_OK;
+}
+
+struct StatementIO {
+    std::vector<A4> commitments;
+    std::vector<F4> publics;
+};
+
+// Statement construction, prover side.  RNG consumption order is part of the scenario definition.
+template <class C> static int scenario_prover(ConstraintSystem<C>& cs, const PedersenGens<C>& pc, ChaChaRng& prng, int sc, const u64* prm, StatementIO& io) {
+    typedef Fld<typename C::Fr> S; typedef typename C::Fr FrP; typedef ConstraintSystem<C> CS;
+    auto commit = [&](const F4& val, const F4& blind) {  // Prover::commit (prover.rs:327-341)
+        u32 i = (u32)cs.v.size();
+        cs.v.push_back(val); cs.v_blinding.push_back(blind);
+        A4 Vp = pc.commit(val, blind);
+        TP<C>::append_point(*cs.tr, "V", Vp);
+        io.commitments.push_back(Vp);
+        return Var{VK_COMMITTED, i};
+    };
+    switch (sc) {
+        case SC_SHUFFLE: {
+            size_t k = prm[0];
+            std::vector<F4> in(k), out(k);
+            for (auto& x : in) x = S::from_u64(prng.next_u64());
+            for (size_t i = 0; i < k; i++) out[i] = in[(i + 1) % k];
+            cs.tr->append_message("dom-sep", "ShuffleProof"); cs.tr->append_u64("k", k);
+            std::vector<Var> xv(k), yv(k);
+            for (size_t i = 0; i < k; i++) { F4 b = rand_fe<FrP>(prng); xv[i] = commit(in[i], b); }
+            for (size_t i = 0; i < k; i++) { F4 b = rand_fe<FrP>(prng); yv[i] = commit(out[i], b); }
+            return shuffle_gadget<C>(cs, xv, yv);
+        }
+        case SC_RANGE: {
+            u64 val = prm[1];
+            F4 b = rand_fe<FrP>(prng);
+            Var var = commit(S::from_u64(val), b);
+            return range_gadget<C>(cs, cs.lc_var(var), &val, prm[0]);
+        }
+        case SC_EXAMPLE: {
+            Var vars[5];
+            for (int i = 0; i < 5; i++) { F4 b = rand_fe<FrP>(prng); vars[i] = commit(S::from_u64(prm[i]), b); }
+            LinComb a = cs.lc_var(vars[0]); CS::lc_add(a, cs.lc_var(vars[1]));
+            LinComb bb = cs.lc_var(vars[2]); CS::lc_add(bb, cs.lc_var(vars[3]));
+            Var o[3]; cs.multiply(a, bb, o);
+            LinComb c = cs.lc_var(vars[4]); CS::lc_add(c, cs.lc_const(S::from_u64(prm[5]))); CS::lc_sub(c, cs.lc_var(o[2]));
+            cs.constrain(c);
+            return BP_OK;
+        }
+        case SC_SQUARE_CHAIN: {
+            size_t N = prm[0];
+            F4 x0 = S::from_u64(prng.next_u64()), b = rand_fe<FrP>(prng), last = x0;
+            for (size_t i = 0; i < N; i++) last = S::sqr(last);
+            if (prm[1]) last = S::add(last, S::one());
+            Var cur = commit(x0, b), o[3];
+            io.publics.push_back(last);
+            for (size_t i = 0; i < N; i++) { cs.multiply(cs.lc_var(cur), cs.lc_var(cur), o); cur = o[2]; }
+            LinComb lc = cs.lc_var(cur); CS::lc_sub(lc, cs.lc_const(last)); cs.constrain(lc);
+            return BP_OK;
+        }
+        case SC_MULTI_RANGE: {
+            size_t count = prm[0], nbits = prm[1];
+            for (size_t j = 0; j < count; j++) {
+                u64 val = prng.next_u64();
+                if (nbits < 64) val &= (((u64)1 << nbits) - 1);
+                if (prm[2] && j == count - 1) val = nbits < 64 ? ((u64)1 << nbits) : val;
+                F4 b = rand_fe<FrP>(prng);
+                Var var = commit(S::from_u64(val), b);
+                int rc = range_gadget<C>(cs, cs.lc_var(var), &val, nbits);
+                if (rc) return rc;
+            }
+            return BP_OK;
+        }
+    }
+    return BP_E_ARG;
+}
+template <class C> static int scenario_verifier(ConstraintSystem<C>& cs, int sc, const u64* prm, const StatementIO& io) {
+    typedef Fld<typename C::Fr> S; typedef ConstraintSystem<C> CS;
+    auto commit = [&](const A4& Vp) {  // Verifier::commit (verifier.rs:279-287)
+        u32 i = (u32)cs.V.size(); cs.V.push_back(Vp); TP<C>::append_point(*cs.tr, "V", Vp); return Var{VK_COMMITTED, i};
+    };
+    switch (sc) {
+        case SC_SHUFFLE: {
+            size_t k = prm[0];
+            if (io.commitments.size() != 2 * k) return BP_E_ARG;
+            cs.tr->append_message("dom-sep", "ShuffleProof"); cs.tr->append_u64("k", k);
+            std::vector<Var> xv(k), yv(k);
+            for (size_t i = 0; i < k; i++) xv[i] = commit(io.commitments[i]);
+            for (size_t i = 0; i < k; i++) yv[i] = commit(io.commitments[k + i]);
+            return shuffle_gadget<C>(cs, xv, yv);
+        }
+        case SC_RANGE: { if (io.commitments.size() != 1) return BP_E_ARG; Var var = commit(io.commitments[0]); return range_gadget<C>(cs, cs.lc_var(var), nullptr, prm[0]); }
+        case SC_EXAMPLE: {
+            if (io.commitments.size() != 5) return BP_E_ARG;
+            Var vars[5];
+            for (int i = 0; i < 5; i++) vars[i] = commit(io.commitments[i]);
+            LinComb a = cs.lc_var(vars[0]); CS::lc_add(a, cs.lc_var(vars[1]));
+            LinComb bb = cs.lc_var(vars[2]); CS::lc_add(bb, cs.lc_var(vars[3]));
+            Var o[3]; cs.multiply(a, bb, o);
+            LinComb c = cs.lc_var(vars[4]); CS::lc_add(c, cs.lc_const(S::from_u64(prm[5]))); CS::lc_sub(c, cs.lc_var(o[2]));
+            cs.constrain(c);
+            return BP_OK;
+        }
+        case SC_SQUARE_CHAIN: {
+            if (io.commitments.size() != 1 || io.publics.size() != 1) return BP_E_ARG;
+            Var cur = commit(io.commitments[0]), o[3];
+            for (size_t i = 0; i < prm[0]; i++) { cs.multiply(cs.lc_var(cur), cs.lc_var(cur), o); cur = o[2]; }
+            LinComb lc = cs.lc_var(cur); CS::lc_sub(lc, cs.lc_const(io.publics[0])); cs.constrain(lc);
+            return BP_OK;
+        }
+        case SC_MULTI_RANGE: {
+            if (io.commitments.size() != prm[0]) return BP_E_ARG;
+            for (size_t j = 0; j < prm[0]; j++) { Var var = commit(io.commitments[j]); int rc = range_gadget<C>(cs, cs.lc_var(var), nullptr, prm[1]); if (rc) return rc; }
+            return BP_OK;
+        }
+    }
+    return BP_E_ARG;
+}
+
+// ---- R1CSProof (src/r1cs/proof.rs:27-91) ---------------------------------------------------------------------
+struct ProofData {
+    A4 A_I1, A_O1, S1, A_I2, A_O2, S2, T_1, T_3, T_4, T_5, T_6;
+    F4 t_x, t_x_blinding, e_blinding;
+    std::vector<A4> L_vec, R_vec;
+    F4 a, b;
+};
+template <class C> static std::vector<u8> proof_to_bytes(const ProofData& p) {
+    typedef Fld<typename C::Fr> S;
+    std::vector<u8> out;
+    auto pt = [&](const A4& q) { u8 b[33]; Grp<C>::ser_compressed(b, q); out.insert(out.end(), b, b + 33); };
+    auto sc = [&](const F4& s) { u8 b[32]; S::to_bytes(b, s); out.insert(out.end(), b, b + 32); };
+    auto vec = [&](const std::vector<A4>& v) { u64 n = v.size(); out.insert(out.end(), (u8*)&n, (u8*)&n + 8); for (auto& q : v) pt(q); };
+    pt(p.A_I1); pt(p.A_O1); pt(p.S1); pt(p.A_I2); pt(p.A_O2); pt(p.S2); pt(p.T_1); pt(p.T_3); pt(p.T_4); pt(p.T_5); pt(p.T_6);
+    sc(p.t_x); sc(p.t_x_blinding); sc(p.e_blinding); vec(p.L_vec); vec(p.R_vec); sc(p.a); sc(p.b);
+    return out;
+}
+template <class C> static int proof_from_bytes(ProofData& p, const u8* d, size_t n) {
+    typedef Fld<typename C::Fr> S;
+    size_t pos = 0;
+    auto pt = [&](A4& q) { if (pos + 33 > n) return false; bool ok = Grp<C>::deser_compressed(q, d + pos); pos += 33; return ok; };
+    auto sc = [&](F4& s) { if (pos + 32 > n) return false; bool ok = S::from_bytes(s, d + pos); pos += 32; return ok; };
+    auto vec = [&](std::vector<A4>& v) {
+        if (pos + 8 > n) return false;
+        u64 len; memcpy(&len, d + pos, 8); pos += 8;
+        if (len > (n - pos) / 33) return false;
+        v.resize(len);
+        for (auto& q : v) if (!pt(q)) return false;
+        return true;
+    };
+    bool ok = pt(p.A_I1) && pt(p.A_O1) && pt(p.S1) && pt(p.A_I2) && pt(p.A_O2) && pt(p.S2) && pt(p.T_1) && pt(p.T_3) && pt(p.T_4) && pt(p.T_5) &&
+              pt(p.T_6) && sc(p.t_x) && sc(p.t_x_blinding) && sc(p.e_blinding) && vec(p.L_vec) && vec(p.R_vec) && sc(p.a) && sc(p.b);
+    return ok ? BP_OK : BP_E_FORMAT;
+}
+
+static inline size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+
+}  // namespace host
+}  // namespace arkbp

@@ -92,7 +92,7 @@ __device__ __forceinline__ int msm_digit(const u32 k[8], int w, int c, u32& carr
     return (int)d - (int)(carry << c);
 }
 
-// 1. digits + histogram.  scalars_mont: words are ark Montgomery form (R = 2^256), else canonical.
+// 1. digits + histogram.  scalars_mont: 0 canonical integers, 1 ark Montgomery words, 2 resident layout.
 template <class C> __global__ void k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl,
                                                 int scalars_mont) {
     typedef typename C::Fr Fr;
@@ -100,8 +100,11 @@ template <class C> __global__ void k_msm_digits(const u32* __restrict__ scalars,
     if (i >= pl.n) return;
     u32 k[8];
     load_words8(k, scalars + (size_t)i * 8);
-    if (scalars_mont) {
+    if (scalars_mont == 1) {          // ark Montgomery words (R = 2^256)
         Fe s = fe_load_ark<Fr>(k);
+        fe_store_canon<Fr>(k, s);
+    } else if (scalars_mont == 2) {   // the engine's resident layout (packed radix-2^29 Montgomery form)
+        Fe s = fe_unpack(k);
         fe_store_canon<Fr>(k, s);
     }
     store_words8(canon + (size_t)i * 8, k);

@@ -1,0 +1,156 @@
+// R1CS prover / verifier vector kernels for gfx950 — the O(N) field work of
+// `Prover::prove_and_return_transcript` (/root/reference/src/r1cs/prover.rs:671-703, 744-756, 781-789,
+// with util.rs:75-102) and of `Verifier::verification_scalars` (src/r1cs/verifier.rs:465-514,
+// inner_product_proof.rs:279-311).  Vectors are HBM-resident in the engine's scalar layout (32 B,
+// radix-2^29 Montgomery form, packed); nothing of length N returns to the host.
+//
+//   k_r1cs_poly_t     one pass over a_L,a_R,a_O,s_L,s_R,wL,wR,wO: forms l1,l2,l3 / r0,r1,r3 in registers
+//                     (prover.rs:685-698) and reduces the six coefficient inner products t1..t6
+//                     (util.rs:75-93) — the reference materialises 6 vectors and makes 8 passes
+//   k_r1cs_sum6       finishes the per-workgroup partials
+//   k_r1cs_poly_eval  l_vec = l(x), r_vec = r(x) with the power-of-two padding (prover.rs:746-756) and the
+//                     IPA factor vectors G_factors / H_factors (prover.rs:781-789), written once
+//   k_vfy_scalars     g_scalars / h_scalars of the verifier's mega-check (verifier.rs:492-514) with s[i]
+//                     evaluated in closed form from the squared challenges (inner_product_proof.rs:302-311)
+#pragma once
+#include "ipa.cuh"
+
+namespace arkbp {
+
+// x^e from a table of x^(2^k) (resident words), e < 2^32
+template <class F> __device__ __forceinline__ Fe pow_from_table(const u32* __restrict__ tab, u32 e) {
+    Fe r = fe_one<F>();
+#pragma unroll 1
+    for (int k = 0; e; k++, e >>= 1)
+        if (e & 1) r = fe_mul<F>(r, load_fe_dev<F>(tab + (size_t)k * 8));
+    return r;
+}
+
+// ypow: 64 x 8 words: y^(2^k) for k < 32, then y^-(2^k) for k < 32.
+// partials: gridDim.x x 6 x 8 words.
+template <class C> __global__ void __launch_bounds__(256)
+k_r1cs_poly_t(const u32* __restrict__ aL, const u32* __restrict__ aR, const u32* __restrict__ aO, const u32* __restrict__ sL,
+              const u32* __restrict__ sR, const u32* __restrict__ wL, const u32* __restrict__ wR, const u32* __restrict__ wO,
+              const u32* __restrict__ ypow, u32 n, u32* __restrict__ partials) {
+    typedef typename C::Fr F;
+    __shared__ u32 sh[9 * 256];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fe t[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) t[k] = fe_zero<F>();
+    if (i < n) {
+        const Fe yi = pow_from_table<F>(ypow, i), yni = pow_from_table<F>(ypow + 32 * 8, i);
+        const size_t o = (size_t)i * 8;
+        const Fe l1 = fe_wred<F>(fe_norm(fe_add(load_fe_dev<F>(aL + o), fe_mul<F>(yni, load_fe_dev<F>(wR + o)))));
+        const Fe l2 = load_fe_dev<F>(aO + o), l3 = load_fe_dev<F>(sL + o);
+        const Fe r0 = fe_wred<F>(fe_sub<F, 4>(load_fe_dev<F>(wO + o), yi));
+        const Fe r1 = fe_wred<F>(fe_norm(fe_add(fe_mul<F>(yi, load_fe_dev<F>(aR + o)), load_fe_dev<F>(wL + o))));
+        const Fe r3 = fe_mul<F>(yi, load_fe_dev<F>(sR + o));
+        t[0] = fe_mul<F>(l1, r0);                                                   // t1 = <l1,r0>
+        t[1] = fe_addr<F>(fe_mul<F>(l1, r1), fe_mul<F>(l2, r0));                    // t2 = <l1,r1> + <l2,r0>
+        t[2] = fe_addr<F>(fe_mul<F>(l2, r1), fe_mul<F>(l3, r0));                    // t3 = <l2,r1> + <l3,r0>
+        t[3] = fe_addr<F>(fe_mul<F>(l1, r3), fe_mul<F>(l3, r1));                    // t4 = <l1,r3> + <l3,r1>
+        t[4] = fe_mul<F>(l2, r3);                                                   // t5 = <l2,r3>
+        t[5] = fe_mul<F>(l3, r3);                                                   // t6 = <l3,r3>
+    }
+#pragma unroll 1
+    for (int k = 0; k < 6; k++) {
+        Fe s = block_sum_fe<F>(fe_wred<F>(t[k]), sh);
+        if (threadIdx.x == 0) store_fe_dev<F>(partials + ((size_t)blockIdx.x * 6 + k) * 8, s);
+    }
+}
+// out: cnt x 8 words, ark Montgomery layout (read by the host)
+template <class C> __global__ void __launch_bounds__(256) k_r1cs_sum(const u32* __restrict__ partials, u32 nparts, u32 cnt, u32* __restrict__ out) {
+    typedef typename C::Fr F;
+    __shared__ u32 sh[9 * 256];
+    for (u32 k = 0; k < cnt; k++) {
+        Fe s = fe_zero<F>();
+        for (u32 j = threadIdx.x; j < nparts; j += 256) s = fe_addr<F>(s, load_fe_dev<F>(partials + ((size_t)j * cnt + k) * 8));
+        s = block_sum_fe<F>(s, sh);
+        if (threadIdx.x == 0) {
+            u32 w[8];
+            fe_store_ark<F>(w, s);
+            store_words8(out + (size_t)k * 8, w);
+        }
+    }
+}
+
+// x, u: ark Montgomery words.  Writes l_vec, r_vec, Gf, Hf for i < N (padded length).
+template <class C> __global__ void __launch_bounds__(256)
+k_r1cs_poly_eval(const u32* __restrict__ aL, const u32* __restrict__ aR, const u32* __restrict__ aO, const u32* __restrict__ sL,
+                 const u32* __restrict__ sR, const u32* __restrict__ wL, const u32* __restrict__ wR, const u32* __restrict__ wO,
+                 const u32* __restrict__ ypow, u32 n, u32 n1, u32 N, Words8 xw, Words8 uw, u32* __restrict__ lvec, u32* __restrict__ rvec,
+                 u32* __restrict__ Gf, u32* __restrict__ Hf) {
+    typedef typename C::Fr F;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const Fe x = fe_load_ark<F>(xw.w);
+    const Fe yi = pow_from_table<F>(ypow, i), yni = pow_from_table<F>(ypow + 32 * 8, i);
+    const size_t o = (size_t)i * 8;
+    Fe lv, rv;
+    if (i < n) {
+        const Fe l1 = fe_wred<F>(fe_norm(fe_add(load_fe_dev<F>(aL + o), fe_mul<F>(yni, load_fe_dev<F>(wR + o)))));
+        const Fe l2 = load_fe_dev<F>(aO + o), l3 = load_fe_dev<F>(sL + o);
+        const Fe r0 = fe_wred<F>(fe_sub<F, 4>(load_fe_dev<F>(wO + o), yi));
+        const Fe r1 = fe_wred<F>(fe_norm(fe_add(fe_mul<F>(yi, load_fe_dev<F>(aR + o)), load_fe_dev<F>(wL + o))));
+        const Fe r3 = fe_mul<F>(yi, load_fe_dev<F>(sR + o));
+        // l(x) = x*(l1 + x*(l2 + x*l3));  r(x) = r0 + x*(r1 + x*(x*r3))     (util.rs:95-102, l0 = r2 = 0)
+        Fe acc = fe_addr<F>(fe_mul<F>(x, l3), l2);
+        acc = fe_addr<F>(fe_mul<F>(acc, x), l1);
+        lv = fe_mul<F>(acc, x);
+        acc = fe_mul<F>(fe_mul<F>(x, r3), x);
+        acc = fe_addr<F>(acc, r1);
+        rv = fe_addr<F>(fe_mul<F>(acc, x), r0);
+    } else {
+        lv = fe_zero<F>();
+        rv = fe_neg<F, 4>(fe_wred<F>(yi));  // padding: r_vec[i] = -y^i (prover.rs:753-756)
+    }
+    store_fe_dev<F>(lvec + o, lv);
+    store_fe_dev<F>(rvec + o, rv);
+    const Fe gf = i < n1 ? fe_one<F>() : fe_load_ark<F>(uw.w);
+    store_fe_dev<F>(Gf + o, gf);
+    store_fe_dev<F>(Hf + o, fe_mul<F>(yni, gf));
+}
+
+// Verifier scalars.  chal: u_sq[k] then u_inv_sq[k] (resident words, creation order), consts: resident words
+// [allinv, x, a, b, u, one-slot unused]; ypow as above (only the inverse half is used).
+// g[i] = u_or_1 * (x * y^-i * wR[i] - a * s[i]),  h[i] = u_or_1 * (y^-i * (x*wL[i] + wO[i] - b*s[N-1-i]) - 1)
+// with wL/wR/wO = 0 for i >= n.  s[i] = allinv * prod_{j: bit j of i set} u_sq[k-1-j]  (ipp :302-311),
+// s[N-1-i] = the same product over the clear bits.  Output: canonical integers, ready for the MSM.
+template <class C> __global__ void __launch_bounds__(256)
+k_vfy_scalars(const u32* __restrict__ wL, const u32* __restrict__ wR, const u32* __restrict__ wO, const u32* __restrict__ ypow,
+              const u32* __restrict__ chal, const u32* __restrict__ consts, u32 n, u32 n1, u32 N, u32 k, u32* __restrict__ g_out,
+              u32* __restrict__ h_out) {
+    typedef typename C::Fr F;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const Fe allinv = load_fe_dev<F>(consts), x = load_fe_dev<F>(consts + 8), a = load_fe_dev<F>(consts + 16), b = load_fe_dev<F>(consts + 24);
+    Fe s_i = allinv, s_rev = allinv;
+#pragma unroll 1
+    for (u32 j = 0; j < k; j++) {
+        const Fe usq = load_fe_dev<F>(chal + (size_t)(k - 1 - j) * 8);
+        if ((i >> j) & 1) s_i = fe_mul<F>(s_i, usq); else s_rev = fe_mul<F>(s_rev, usq);
+    }
+    const Fe yni = pow_from_table<F>(ypow + 32 * 8, i);
+    const size_t o = (size_t)i * 8;
+    Fe g, h;
+    if (i < n) {
+        const Fe ywR = fe_mul<F>(yni, load_fe_dev<F>(wR + o));
+        g = fe_sub<F, 2>(fe_mul<F>(x, ywR), fe_mul<F>(a, s_i));
+        Fe t = fe_addr<F>(fe_mul<F>(x, load_fe_dev<F>(wL + o)), load_fe_dev<F>(wO + o));
+        t = fe_sub<F, 2>(t, fe_mul<F>(b, s_rev));
+        h = fe_sub<F, 2>(fe_mul<F>(yni, t), fe_one<F>());
+    } else {
+        g = fe_neg<F, 2>(fe_mul<F>(a, s_i));
+        h = fe_sub<F, 2>(fe_mul<F>(yni, fe_neg<F, 2>(fe_mul<F>(b, s_rev))), fe_one<F>());
+    }
+    if (i >= n1) {
+        const Fe u = load_fe_dev<F>(consts + 32);
+        g = fe_mul<F>(g, u);
+        h = fe_mul<F>(h, u);
+    }
+    store_fe_canon<F>(g_out + o, g);
+    store_fe_canon<F>(h_out + o, h);
+}
+
+}  // namespace arkbp

@@ -150,3 +150,104 @@ def _ipa_create(self, Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec, chall
 
 
 Engine.ipa_create = _ipa_create
+
+
+# ---- generators / prover ---------------------------------------------------------------------------
+SC_SHUFFLE, SC_RANGE, SC_EXAMPLE, SC_SQUARE_CHAIN, SC_MULTI_RANGE = 0, 1, 2, 3, 4
+
+
+def _gens_derive(self, cap):
+    """BulletproofGens::new(cap, 1) + PedersenGens::default(), installed in HBM"""
+    check(lib().bp_gens_derive(self.ctx, C.c_size_t(cap)), "bp_gens_derive")
+    self.gens_capacity = cap
+
+
+def _gens_upload(self, G_xy, H_xy):
+    G, H = u64arr(G_xy, 8), u64arr(H_xy, 8)
+    assert len(G) == len(H)
+    check(lib().bp_gens_upload(self.ctx, ptr(G), ptr(H), C.c_size_t(len(G))), "bp_gens_upload")
+    self.gens_capacity = len(G)
+
+
+def _gens_download(self, n):
+    G, H = np.zeros((n, 8), dtype=np.uint64), np.zeros((n, 8), dtype=np.uint64)
+    check(lib().bp_gens_download(self.ctx, ptr(G), ptr(H), C.c_size_t(n)), "bp_gens_download")
+    return G, H
+
+
+class Proved:
+    def __init__(self, proof, commitments, publics, timing):
+        self.proof, self.commitments, self.publics, self.timing = proof, commitments, publics, timing
+        self.t_prove, self.t_setup = timing[0], timing[1]
+
+
+def _prove_scenario(self, scenario, params, seed, m_cap=None):
+    prm = np.zeros(8, dtype=np.uint64)
+    prm[: len(params)] = np.array(params, dtype=np.uint64)
+    if m_cap is None:
+        m_cap = 2 * int(prm[0]) + 8
+    buf = C.create_string_buffer(1 << 16)
+    plen = C.c_size_t(len(buf))
+    commits = np.zeros((m_cap, 8), dtype=np.uint64)
+    m, npub = C.c_size_t(0), C.c_size_t(0)
+    pubs = np.zeros((8, 4), dtype=np.uint64)
+    timing = (C.c_double * 8)()
+    check(lib().bp_r1cs_prove_scenario(self.ctx, scenario, ptr(prm), bytes(seed), buf, C.byref(plen), ptr(commits), C.c_size_t(m_cap), C.byref(m),
+                                       ptr(pubs), C.byref(npub), timing), "bp_r1cs_prove_scenario")
+    return Proved(buf.raw[: plen.value], commits[: m.value].copy(), pubs[: npub.value].copy(), list(timing))
+
+
+Engine.gens_derive = _gens_derive
+Engine.gens_upload = _gens_upload
+Engine.gens_download = _gens_download
+Engine.prove_scenario = _prove_scenario
+
+
+class HostTranscript:
+    """The product's merlin::Transcript (host C++), for tests and for driving bp_ipa_create."""
+
+    def __init__(self, label):
+        self.h = C.c_void_p(lib().bp_transcript_new(bytes(label), C.c_size_t(len(label))))
+
+    def __del__(self):
+        try:
+            lib().bp_transcript_free(self.h)
+        except Exception:
+            pass
+
+    def append_message(self, label, msg):
+        lib().bp_transcript_append_message(self.h, bytes(label), bytes(msg), C.c_size_t(len(msg)))
+
+    def append_u64(self, label, x):
+        self.append_message(label, int(x).to_bytes(8, "little"))
+
+    def challenge_bytes(self, label, n):
+        out = C.create_string_buffer(n)
+        lib().bp_transcript_challenge_bytes(self.h, bytes(label), out, C.c_size_t(n))
+        return out.raw
+
+    def append_point(self, curve, label, xy):
+        check(lib().bp_transcript_append_point(curve, self.h, bytes(label), ptr(np.ascontiguousarray(xy, dtype=np.uint64))), "append_point")
+
+    def challenge_scalar(self, curve, label):
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib().bp_transcript_challenge_scalar(curve, self.h, bytes(label), ptr(out)), "challenge_scalar")
+        return out
+
+
+def pedersen_gens(curve):
+    B, Bb = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    check(lib().bp_pedersen_gens(curve, ptr(B), ptr(Bb)), "bp_pedersen_gens")
+    return B, Bb
+
+
+def host_derive_generators(curve, which_H, party, count):
+    out = np.zeros((count, 8), dtype=np.uint64)
+    check(lib().bp_host_derive_generators(curve, int(which_H), party, C.c_size_t(count), ptr(out)), "bp_host_derive_generators")
+    return out
+
+
+def host_sha3_512(msg):
+    out = C.create_string_buffer(64)
+    lib().bp_host_sha3_512(bytes(msg), C.c_size_t(len(msg)), out)
+    return out.raw

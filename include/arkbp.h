@@ -76,11 +76,46 @@ int bp_ipa_create(bp_ctx* ctx, const uint64_t Q_xy[8], const uint64_t* G_factors
                   const uint64_t* H_xy, const uint64_t* a, const uint64_t* b, size_t n, bp_challenge_cb cb, void* user, uint64_t* L_out_xy,
                   uint64_t* R_out_xy, uint64_t a_out[4], uint64_t b_out[4]);
 
+/* ---- generators -----------------------------------------------------------------------------------
+ * bp_gens_derive replaces `BulletproofGens::new(cap, 1)` + `PedersenGens::default()` (src/generators.rs:174-221,
+ * 47-66): derives party 0's G/H tables on the host cores and installs them in HBM (resident for the life of
+ * the ctx; the reference clones them into fresh Vecs per proof, src/r1cs/prover.rs:796-797).
+ * bp_gens_upload installs tables the caller already holds (ark layout). */
+int bp_gens_derive(bp_ctx* ctx, size_t gens_capacity);
+int bp_gens_upload(bp_ctx* ctx, const uint64_t* G_xy, const uint64_t* H_xy, size_t gens_capacity);
+int bp_gens_download(bp_ctx* ctx, uint64_t* G_xy, uint64_t* H_xy, size_t n);
+/* PedersenGens::default() -> (B, B_blinding); host only */
+int bp_pedersen_gens(int curve, uint64_t B_xy[8], uint64_t B_blinding_xy[8]);
+/* GeneratorsChain for label 'G'|'H' || LE32(party) (src/generators.rs:71-121), first `count` points; host only */
+int bp_host_derive_generators(int curve, int which_H, uint32_t party, size_t count, uint64_t* out_xy);
+
+/* ---- host transcript: merlin::Transcript + TranscriptProtocol (src/transcript.rs:45-102); host only ---- */
+void* bp_transcript_new(const uint8_t* label, size_t n);
+void bp_transcript_free(void* t);
+void bp_transcript_append_message(void* t, const char* label, const uint8_t* msg, size_t n);
+void bp_transcript_challenge_bytes(void* t, const char* label, uint8_t* out, size_t n);
+int bp_transcript_append_point(int curve, void* t, const char* label, const uint64_t xy[8]);
+int bp_transcript_challenge_scalar(int curve, void* t, const char* label, uint64_t out[4]);
+int bp_host_sha3_512(const uint8_t* msg, size_t n, uint8_t out[64]);
+
+/* ---- r1cs::Prover::prove -------------------------------------------------------------------------
+ * Replaces `Prover::new` + commits + gadget + `prove(prng, bp_gens)` (src/r1cs/prover.rs:291-341, 444-831)
+ * for the statement families the reference's tests and benches build ("scenarios": 0 k-shuffle
+ * benches/r1cs_secq256k1.rs:34-112, 1 range proof tests/r1cs_secq256k1.rs:361-445, 2 example gadget
+ * :216-267, 3 square chain and 4 multi-range: this build's synthetic large circuits).  params: 8 u64
+ * (scenario-specific), seed: ChaCha20 seed of the external prng.  Outputs: compressed proof bytes
+ * (`R1CSProof::to_bytes`, src/r1cs/proof.rs:74-81), the V commitments, scenario publics.
+ * timing[8] (seconds): [0] inside prove(), [1] statement construction, [2] TranscriptRng draws, [3] uploads,
+ * [4] commitment MSMs, [5] flattened_constraints, [6] polynomial kernels, [7] inner-product argument. */
+int bp_r1cs_prove_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, const uint8_t seed[32], uint8_t* proof_out, size_t* proof_len,
+                           uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, double* timing);
+
 /* ---- profiling: HIP-event time of the dominant kernel of the last call, on the ctx stream ---------- */
 #define BP_K_MSM_ACCUM 0   /* bucket accumulation (k_msm_accum) */
 #define BP_K_MSM_TOTAL 1   /* all MSM kernels of the call, first launch to last */
 #define BP_K_IPA_SCALARS 2 /* k_ipa_scalars + k_ipa_ip_finish of one round */
 #define BP_K_IPA_FOLD 3    /* k_ipa_fold_ab + k_ipa_fold_pts of one round */
+#define BP_K_R1CS_POLY 4   /* k_r1cs_poly_t / k_r1cs_poly_eval */
 #define BP_K_COUNT 8
 int bp_ctx_set_profiling(bp_ctx* ctx, int enabled);
 /* accumulated milliseconds and launch count since the last reset */

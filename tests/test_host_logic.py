@@ -1,0 +1,62 @@
+"""CPU tests of the PRODUCT's host-side logic (no GPU): its own Merlin/STROBE, SHA3-512, ChaCha20-based
+challenge scalars, PedersenGens::default and GeneratorsChain — against published vectors and against the
+independent oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def E():
+    from ark_bulletproofs_amd import build
+
+    build.build()
+    from ark_bulletproofs_amd import engine
+
+    return engine
+
+
+def test_product_sha3(E):
+    for n in [0, 1, 71, 72, 73, 500]:
+        m = bytes((i * 5 + 1) & 255 for i in range(n))
+        assert E.host_sha3_512(m) == hashlib.sha3_512(m).digest()
+
+
+def test_product_merlin_vectors(E):
+    t = E.HostTranscript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    t = E.HostTranscript(b"test protocol")
+    t.append_message(b"step1", b"some data")
+    data = bytes([99]) * 1024
+    for _ in range(32):
+        chl = t.challenge_bytes(b"challenge", 32)
+        t.append_message(b"bigdata", data)
+        t.append_message(b"challengedata", chl)
+    assert chl.hex() == "a8c933f54fae76e3f9bea93648c1308e7dfa2152dd51674ff3ca438351cf003c"
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_product_transcript_protocol_matches_oracle(E, oracle, curve):
+    O = oracle
+    G, H = O.bp_gens(curve, 4)
+    tp, to = E.HostTranscript(b"xyz"), O.Transcript(b"xyz")
+    for i, p in enumerate(list(G) + [np.zeros(8, dtype=np.uint64)]):
+        tp.append_point(curve, b"P", p)
+        to.append_point(curve, b"P", p)
+        assert (tp.challenge_scalar(curve, b"c") == to.challenge_scalar(curve, b"c")).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_product_generators_match_oracle(E, oracle, curve):
+    O = oracle
+    B, Bb = E.pedersen_gens(curve)
+    Bo, Bbo = O.pedersen_default(curve)
+    assert (B == Bo).all() and (Bb == Bbo).all()
+    n = 300  # > 256 attempts: exercises the threaded path
+    Go, Ho = O.bp_gens(curve, n)
+    assert (E.host_derive_generators(curve, 0, 0, n) == Go).all()
+    assert (E.host_derive_generators(curve, 1, 0, n) == Ho).all()
+    g1, _ = O.bp_gens_party(curve, 8, 3)
+    assert (E.host_derive_generators(curve, 0, 3, 8) == g1).all()
