@@ -9,12 +9,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libarkbp_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["arkbp.hip"]
-HEADERS = ["arkbp_params.h", "fp29.cuh", "ec.cuh", "msm.cuh", "host_math.hpp", os.path.join("..", "..", "include", "arkbp.h")]
+HEADERS = ["arkbp_params.h", "fp29.cuh", "ec.cuh", "msm.cuh", "host_math.hpp", "keccak_unrolled.inc", "r1cs_host.inc", os.path.join("..", "..", "include", "arkbp.h")]
 
 
 def _deps():
     out = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    out += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".hpp", ".hip", ".h"))]
+    out += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".hpp", ".hip", ".h", ".inc"))]
     return sorted(set(out))
 
 
@@ -28,7 +28,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Xarch_host", "-march=x86-64-v3",
            "-Wno-unused-result", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

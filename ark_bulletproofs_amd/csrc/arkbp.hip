@@ -121,12 +121,15 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (n >= (1u << 31)) { g_err = "msm: n too large"; return BP_E_ARG; }
     hipStream_t st = ctx->stream;
     MsmPlan pl = msm_plan(n, C::Fr::BITS);
-    constexpr int NL = MSM_MAXLVL + 1;
+    constexpr int NL = MSM_NLMAX;
+    int nl = 2;  // levels 0..nl-1 can be needed: 16^(nl-1) >= n
+    { u64 cap = MSM_CH; while (cap < n && nl < NL) { cap *= MSM_CH; nl++; } }
     const size_t Bp1 = (size_t)pl.B + 1;
+    const u32 ntiles = (pl.B + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
     BPCHK(ctx->canon.ensure(n * 32));
     BPCHK(ctx->hist.ensure(pl.B * 4));
     BPCHK(ctx->lvl_off.ensure(Bp1 * NL * 4));
-    BPCHK(ctx->totals.ensure((NL + 1) * 4));
+    BPCHK(ctx->totals.ensure((NL + 1) * 4 + (size_t)ntiles * (NL + 1) * 4));
     BPCHK(ctx->cursor.ensure(pl.B * 4));
     BPCHK(ctx->entries.ensure(n * pl.W * 4));
     BPCHK(ctx->Tbuf.ensure((size_t)pl.W * pl.c * 96));
@@ -139,13 +142,17 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     }
     ScopedK total(ctx, BP_K_MSM_TOTAL);
     u32* lvl = ctx->lvl_off.as<u32>();
+    u32* d_tot = ctx->totals.as<u32>();
+    u32* d_tiles = d_tot + (NL + 1);
     HIPCHK(hipMemsetAsync(ctx->hist.p, 0, pl.B * 4, st));
     const int TB = 256;
     const u32 gb = (u32)((n + TB - 1) / TB);
     hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont);
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ctx->hist.as<u32>(), lvl, ctx->totals.as<u32>(), pl.B);
+    hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl);
+    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
+    hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl);
     HIPCHK(hipMemcpyAsync(ctx->cursor.p, lvl, pl.B * 4, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_totals, ctx->totals.p, (NL + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 1) * 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(k_msm_scatter, dim3(gb), dim3(TB), 0, st, ctx->canon.as<u32>(), ctx->cursor.as<u32>(), ctx->entries.as<u32>(), pl);
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
@@ -155,7 +162,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     // levels: 1 = chunks of entries; k >= 2 = chunks of level k-1 partials; stop when a bucket holds <= 1
     int K = 1;
     { u64 cap = MSM_CH; while (cap < maxcnt) { cap *= MSM_CH; K++; } }
-    if (K > MSM_MAXLVL) { g_err = "msm: bucket population exceeds the reduction depth"; return BP_E_ARG; }
+    if (K >= nl) { g_err = "msm: bucket population exceeds the reduction depth"; return BP_E_ARG; }
     BPCHK(ctx->lvA.ensure((size_t)tot[1] * 96));
     if (K >= 2) BPCHK(ctx->lvB.ensure((size_t)tot[2] * 96));
     {

@@ -20,31 +20,8 @@ namespace arkbp {
 namespace host {
 
 // ---- Keccak-f[1600], 64-bit lanes, theta/rho-pi/chi/iota per round -----------------------------------
-static inline u64 rol(u64 x, unsigned s) { return (x << s) | (x >> (64 - s)); }
-static inline void keccakf(u64 s[25]) {
-    static const u64 rc[24] = {0x1ULL, 0x8082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x808bULL, 0x80000001ULL,
-                               0x8000000080008081ULL, 0x8000000000008009ULL, 0x8aULL, 0x88ULL, 0x80008009ULL, 0x8000000aULL,
-                               0x8000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
-                               0x8000000000008002ULL, 0x8000000000000080ULL, 0x800aULL, 0x800000008000000aULL,
-                               0x8000000080008081ULL, 0x8000000000008080ULL, 0x80000001ULL, 0x8000000080008008ULL};
-    static const unsigned rot[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-    static const unsigned pil[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
-    for (int r = 0; r < 24; r++) {
-        u64 bc[5];
-        for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
-        for (int i = 0; i < 5; i++) {
-            u64 t = bc[(i + 4) % 5] ^ rol(bc[(i + 1) % 5], 1);
-            for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
-        }
-        u64 t = s[1];
-        for (int i = 0; i < 24; i++) { unsigned j = pil[i]; u64 b = s[j]; s[j] = rol(t, rot[i]); t = b; }
-        for (int j = 0; j < 25; j += 5) {
-            u64 a0 = s[j], a1 = s[j + 1], a2 = s[j + 2], a3 = s[j + 3], a4 = s[j + 4];
-            s[j] = a0 ^ (~a1 & a2); s[j + 1] = a1 ^ (~a2 & a3); s[j + 2] = a2 ^ (~a3 & a4); s[j + 3] = a3 ^ (~a4 & a0); s[j + 4] = a4 ^ (~a0 & a1);
-        }
-        s[0] ^= rc[r];
-    }
-}
+#include "keccak_unrolled.inc"
+static inline void keccakf(u64 s[25]) { keccakf_unrolled((uint64_t*)s); }
 static inline void sha3_512(u8 out[64], const u8* m, size_t n) {
     u64 s[25] = {0};
     u8* b = (u8*)s;

@@ -5,8 +5,8 @@
 // affine coordinates ark produces; this one is laid out for 256 CUs x 64-lane waves:
 //
 //   1. k_msm_digits    signed c-bit digits of every scalar (ark Montgomery or canonical words in HBM),
-//                      per-(window,|digit|) histogram (global atomics, buckets >> lanes for random data)
-//   2. k_msm_scan      exclusive scans: entry offsets + chunk offsets for every reduction level
+//                      per-(window,|digit|) histogram: global atomics, wave-aggregated when lanes collide
+//   2. k_msm_scan_*    exclusive scans: entry offsets + chunk offsets for every reduction level
 //   3. k_msm_scatter   counting-sort scatter of (term index, sign) into bucket order
 //   4. k_msm_accum     level 1: one lane per CH-entry chunk of a bucket, mixed Jacobian+affine adds of
 //                      gathered 64-byte bases.  Chunking (not "one lane per bucket") keeps skewed inputs
@@ -92,84 +92,151 @@ __device__ __forceinline__ int msm_digit(const u32 k[8], int w, int c, u32& carr
     return (int)d - (int)(carry << c);
 }
 
+// Wave-aggregated counting.  Skewed inputs (the short top window, 0/1 witness vectors, repeated scalars) put
+// most lanes of a wave on the same counter; then one lane adds the whole group's count.  For spread keys the
+// probe (one ballot) fails and every lane issues its own atomic.  Returns this lane's slot when `cursor`.
+__device__ __forceinline__ u32 wave_count(u32* __restrict__ ctr, u32 key, bool valid) {
+    const u32 lane = __lane_id();
+    u64 act = __ballot(valid);
+    u32 pos = 0;
+    if (!act) return 0;
+    const int lead0 = __ffsll((unsigned long long)act) - 1;
+    const u32 k0 = __shfl(key, lead0);
+    const u64 m0 = __ballot(valid && key == k0);
+    if (__popcll(m0) < 4) {
+        if (valid) pos = atomicAdd(&ctr[key], 1u);
+        return pos;
+    }
+    while (act) {
+        const int lead = __ffsll((unsigned long long)act) - 1;
+        const u32 kk = __shfl(key, lead);
+        const u64 m = __ballot(valid && key == kk);
+        u32 base = 0;
+        if ((int)lane == lead) base = atomicAdd(&ctr[kk], (u32)__popcll(m));
+        base = __shfl(base, lead);
+        if (valid && key == kk) pos = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+        act &= ~m;
+    }
+    return pos;
+}
+
 // 1. digits + histogram.  scalars_mont: 0 canonical integers, 1 ark Montgomery words, 2 resident layout.
-template <class C> __global__ void k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl,
-                                                int scalars_mont) {
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont) {
     typedef typename C::Fr Fr;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pl.n) return;
+    const bool live = i < pl.n;
     u32 k[8];
-    load_words8(k, scalars + (size_t)i * 8);
-    if (scalars_mont == 1) {          // ark Montgomery words (R = 2^256)
-        Fe s = fe_load_ark<Fr>(k);
-        fe_store_canon<Fr>(k, s);
-    } else if (scalars_mont == 2) {   // the engine's resident layout (packed radix-2^29 Montgomery form)
-        Fe s = fe_unpack(k);
-        fe_store_canon<Fr>(k, s);
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = 0;
+    if (live) {
+        load_words8(k, scalars + (size_t)i * 8);
+        if (scalars_mont == 1) {          // ark Montgomery words (R = 2^256)
+            Fe s = fe_load_ark<Fr>(k);
+            fe_store_canon<Fr>(k, s);
+        } else if (scalars_mont == 2) {   // the engine's resident layout (packed radix-2^29 Montgomery form)
+            Fe s = fe_unpack(k);
+            fe_store_canon<Fr>(k, s);
+        }
+        store_words8(canon + (size_t)i * 8, k);
     }
-    store_words8(canon + (size_t)i * 8, k);
     u32 carry = 0;
     for (int w = 0; w < pl.W; w++) {
-        int d = msm_digit(k, w, pl.c, carry);
-        if (d != 0) atomicAdd(&hist[(u32)w * pl.NB + (u32)(d < 0 ? -d : d) - 1], 1u);
+        const int d = msm_digit(k, w, pl.c, carry);
+        (void)wave_count(hist, (u32)w * pl.NB + (u32)(d < 0 ? -d : d) - 1, live && d != 0);
     }
 }
 
-// 2. scans.  lvl_off[k] (k = 0..MAXLVL) has B+1 entries: level 0 counts entries, level k >= 1 counts
-// ceil(cnt / CH^k) chunks.  totals[k] = lvl_off[k][B]; totals[MAXLVL+1] = max bucket population.
-__global__ void k_msm_scan(const u32* __restrict__ hist, u32* __restrict__ lvl_off, u32* __restrict__ totals, u32 B) {
-    constexpr int NL = MSM_MAXLVL + 1;
-    __shared__ u32 sh[1024][NL + 1];
-    const u32 tid = threadIdx.x, nt = blockDim.x;
-    const u32 per = (B + nt - 1) / nt;
-    const u32 lo = min(B, tid * per), hi = min(B, lo + per);
-    u32 sum[NL], mx = 0;
-    for (int k = 0; k < NL; k++) sum[k] = 0;
-    for (u32 b = lo; b < hi; b++) {
-        u32 cnt = hist[b];
-        mx = max(mx, cnt);
-        u32 v = cnt;
-        for (int k = 0; k < NL; k++) { sum[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
+// 2. scans.  lvl_off[k] (k = 0..nl-1) has B+1 entries: level 0 counts entries, level k >= 1 counts
+// ceil(cnt / CH^k) chunks.  totals[k] = lvl_off[k][B]; totals[NLMAX] = max bucket population.
+// Three launches: per-tile sums, one-workgroup scan of the tile sums, per-tile exclusive scan.
+static constexpr int MSM_NLMAX = MSM_MAXLVL + 1;
+static constexpr int MSM_SCAN_TILE = 2048;  // buckets per workgroup (256 lanes x 8)
+
+__global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ hist, u32* __restrict__ tile_sums, u32 B, int nl) {
+    __shared__ u32 sh[MSM_NLMAX + 1][4];
+    const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
+    u32 sum[MSM_NLMAX + 1];
+    for (int k = 0; k <= MSM_NLMAX; k++) sum[k] = 0;
+    for (u32 j = 0; j < 8; j++) {
+        const u32 b = base + j;
+        u32 v = b < B ? hist[b] : 0;
+        sum[MSM_NLMAX] = max(sum[MSM_NLMAX], v);
+        for (int k = 0; k < nl; k++) { sum[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
     }
-    for (int k = 0; k < NL; k++) sh[tid][k] = sum[k];
-    sh[tid][NL] = mx;
+    for (int k = 0; k <= MSM_NLMAX; k++) {
+        u32 v = sum[k];
+        for (int o = 32; o >= 1; o >>= 1) { u32 t = __shfl_xor(v, o); v = (k == MSM_NLMAX) ? max(v, t) : v + t; }
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
+    }
     __syncthreads();
-    // Hillis-Steele inclusive scan over threads (1024 x NL words; runs once per MSM)
-    for (u32 d = 1; d < nt; d <<= 1) {
-        u32 tmp[NL + 1];
-        const bool has = tid >= d;
-        for (int k = 0; k < NL; k++) tmp[k] = has ? sh[tid - d][k] : 0;
-        tmp[NL] = has ? sh[tid - d][NL] : 0;
-        __syncthreads();
-        for (int k = 0; k < NL; k++) sh[tid][k] += tmp[k];
-        sh[tid][NL] = max(sh[tid][NL], tmp[NL]);
-        __syncthreads();
+    if (threadIdx.x <= MSM_NLMAX) {
+        const int k = threadIdx.x;
+        u32 v = (k == MSM_NLMAX) ? max(max(sh[k][0], sh[k][1]), max(sh[k][2], sh[k][3])) : sh[k][0] + sh[k][1] + sh[k][2] + sh[k][3];
+        tile_sums[(size_t)blockIdx.x * (MSM_NLMAX + 1) + k] = v;
     }
-    u32 run[NL];
-    for (int k = 0; k < NL; k++) run[k] = tid ? sh[tid - 1][k] : 0;
-    for (u32 b = lo; b < hi; b++) {
-        u32 v = hist[b];
-        for (int k = 0; k < NL; k++) { lvl_off[(size_t)k * (B + 1) + b] = run[k]; run[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
+}
+// one workgroup: exclusive scan of the tile sums in place, totals out
+__global__ void __launch_bounds__(64) k_msm_scan_top(u32* __restrict__ tile_sums, u32 ntiles, u32* __restrict__ totals, u32* __restrict__ lvl_off, u32 B) {
+    const int k = threadIdx.x;
+    if (k > MSM_NLMAX) return;
+    u32 run = 0;
+    for (u32 t = 0; t < ntiles; t++) {
+        u32* p = &tile_sums[(size_t)t * (MSM_NLMAX + 1) + k];
+        const u32 v = *p;
+        if (k == MSM_NLMAX) run = max(run, v); else { *p = run; run += v; }
     }
-    if (tid == nt - 1) {
-        for (int k = 0; k < NL; k++) { lvl_off[(size_t)k * (B + 1) + B] = sh[tid][k]; totals[k] = sh[tid][k]; }
-        totals[NL] = sh[tid][NL];
+    totals[k] = run;
+    if (k < MSM_NLMAX) lvl_off[(size_t)k * (B + 1) + B] = run;
+}
+__global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl) {
+    __shared__ u32 sh[MSM_NLMAX][4];
+    const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 cnt[8];
+    u32 sum[MSM_NLMAX];
+    for (int k = 0; k < MSM_NLMAX; k++) sum[k] = 0;
+    for (u32 j = 0; j < 8; j++) {
+        const u32 b = base + j;
+        u32 v = b < B ? hist[b] : 0;
+        cnt[j] = v;
+        for (int k = 0; k < nl; k++) { sum[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
+    }
+    u32 excl[MSM_NLMAX];
+    for (int k = 0; k < nl; k++) {   // inclusive scan across the wave, then exclusive
+        u32 v = sum[k];
+        for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(v, o); if ((int)lane >= o) v += t; }
+        if (lane == 63) sh[k][wv] = v;
+        excl[k] = v - sum[k];
+    }
+    __syncthreads();
+    for (int k = 0; k < nl; k++) {
+        u32 add = tile_sums[(size_t)blockIdx.x * (MSM_NLMAX + 1) + k];
+        for (u32 w2 = 0; w2 < wv; w2++) add += sh[k][w2];
+        excl[k] += add;
+    }
+    for (u32 j = 0; j < 8; j++) {
+        const u32 b = base + j;
+        if (b >= B) break;
+        u32 v = cnt[j];
+        for (int k = 0; k < nl; k++) { lvl_off[(size_t)k * (B + 1) + b] = excl[k]; excl[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
     }
 }
 
 // 3. scatter into bucket order.  cursor starts as a copy of lvl_off[0].
-__global__ void k_msm_scatter(const u32* __restrict__ canon, u32* __restrict__ cursor, u32* __restrict__ entries, MsmPlan pl) {
+__global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ canon, u32* __restrict__ cursor, u32* __restrict__ entries, MsmPlan pl) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pl.n) return;
+    const bool live = i < pl.n;
     u32 k[8];
-    load_words8(k, canon + (size_t)i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = 0;
+    if (live) load_words8(k, canon + (size_t)i * 8);
     u32 carry = 0;
     for (int w = 0; w < pl.W; w++) {
-        int d = msm_digit(k, w, pl.c, carry);
-        if (d != 0) {
-            u32 pos = atomicAdd(&cursor[(u32)w * pl.NB + (u32)(d < 0 ? -d : d) - 1], 1u);
-            entries[pos] = (i << 1) | (d < 0 ? 1u : 0u);
-        }
+        const int d = msm_digit(k, w, pl.c, carry);
+        const bool valid = live && d != 0;
+        const u32 pos = wave_count(cursor, (u32)w * pl.NB + (u32)(d < 0 ? -d : d) - 1, valid);
+        if (valid) entries[pos] = (i << 1) | (d < 0 ? 1u : 0u);
     }
 }
 

@@ -133,6 +133,82 @@ def run_msm(args, rank, world, local):
     return res
 
 
+def run_prove(args, rank, world, local):
+    """cfg3: one R1CS proof of a 2^logn-multiplier circuit per step (square chain: 1 commitment, N multiply
+    gates, q = 2N+1 linear constraints).  `value` = padded multiplication gates / wall seconds inside prove()
+    (SURVEY.md §8d).  For N > 1 ranks prove independent statements (replicas): a single proof's IPA does not
+    shard in this round."""
+    import torch
+
+    import ark_bulletproofs_amd as A
+
+    N = 1 << args.logn
+    eng = A.Engine(curve=args.curve, device=local)
+    t0 = time.perf_counter()
+    eng.gens_derive(N)
+    t_gens = time.perf_counter() - t0
+    seed = bytes([3]) * 32
+    for _ in range(args.warmup):
+        eng.prove_scenario(A.engine.SC_SQUARE_CHAIN, [N, 0], seed, m_cap=8)
+    eng.set_profiling(True)
+    eng.reset_profiling()
+    barrier(world)
+    t0 = time.perf_counter()
+    inside = 0.0
+    stages = np.zeros(8)
+    for _ in range(args.steps):
+        pr = eng.prove_scenario(A.engine.SC_SQUARE_CHAIN, [N, 0], seed, m_cap=8)
+        inside += pr.timing[0]
+        stages += np.array(pr.timing)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([dt, inside], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, inside = float(tt[0].item()), float(tt[1].item())
+    fold_ms, fold_n = eng.kernel_time(3)
+    acc_ms, acc_n = eng.kernel_time(0)
+    msm_ms, msm_n = eng.kernel_time(1)
+    names = ["prove_total", "statement_setup", "transcript_rng", "uploads", "commit_msms", "flatten_constraints", "poly_kernels", "ipa"]
+    res = {
+        "metric": "r1cs_constraints_proved_per_sec", "value": N * world * args.steps / inside, "unit": "constraints/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": inside / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
+        "config": {"workload": "cfg3: 2^%d-constraint R1CS prove (square-chain circuit, m=1, q=2N+1), %s, 1 proof/step/GPU" % (args.logn, ["secq256k1", "zorro"][args.curve]),
+                   "constraints_per_proof": N, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": "replicas x%d" % world,
+                   "wall_ms_per_step_incl_statement_setup": dt / args.steps * 1e3, "gens_derive_s": t_gens,
+                   "stage_ms": {k: float(v) / args.steps * 1e3 for k, v in zip(names, stages)}},
+    }
+    if fold_n:
+        # dominant kernel: the IPA fold (k_ipa_fold_pts): per proof it reads 4*64 B and writes 2*64 B per folded pair
+        # of points plus 4*32 + 2*32 B of scalars, over sum_j n_j = N-1 pairs  => 576 B * (N-1)  (SURVEY.md §8d)
+        per_proof_s = fold_ms / args.steps * 1e-3
+        res["roofline"] = {"bound": "hbm", "kernel": "k_ipa_fold_pts (+k_ipa_fold_ab), all rounds of one proof", "achieved": 576.0 * (N - 1) / per_proof_s / 1e9,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 576.0 * (N - 1) / per_proof_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "avg_kernel_ms": fold_ms / max(fold_n, 1), "fold_ms_per_proof": fold_ms / args.steps,
+                           "msm_kernels_ms_per_proof": msm_ms / args.steps, "msm_accum_ms_per_proof": acc_ms / args.steps,
+                           "note": "integer-VALU-bound path (2 x 256-bit scalar muls per folded point): see DESIGN.md"}
+    if rank == 0 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_prove(args)
+    eng.close()
+    return res
+
+
+def cpu_baseline_prove(args):
+    """CPU restatement of the reference prover (oracle/protocol.hpp: per-element 2-term msm + into_affine in the
+    folds, ark window schedule), 1 thread, bounded sample of the same circuit family."""
+    from oracle import pyoracle as O
+
+    logn = min(args.logn, args.cpu_logn)
+    n = 1 << logn
+    pr = O.r1cs_prove(args.curve, O.SC_SQUARE_CHAIN, [n, 0], bytes([3]) * 32, n, m_cap=8)
+    assert pr.rc == 0
+    return {"value": n / pr.t_prove, "unit": "constraints/s", "cores": 1, "kind": "port",
+            "sample": "square-chain circuit with 2^%d constraints (prove() only, %.1f s), reference algorithm restated in C++" % (logn, pr.t_prove)}
+
+
 def cpu_baseline_msm(args, bases, sc):
     """CPU restatement of ark-ec's VariableBaseMSM (oracle/curve.hpp), 1 thread, same inputs (bounded sample)."""
     from oracle import pyoracle as O
@@ -146,15 +222,17 @@ def cpu_baseline_msm(args, bases, sc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="msm")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="prove", choices=["prove", "msm"])
+    ap.add_argument("--logn", type=int, default=20)
+    ap.add_argument("--cpu-logn", type=int, default=13)
     ap.add_argument("--terms", type=int, default=1 << 16)
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     rank, world, local = dist_setup(args.gpus)
-    res = run_msm(args, rank, world, local)
+    res = run_msm(args, rank, world, local) if args.workload == "msm" else run_prove(args, rank, world, local)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
