@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "../../include/arkbp.h"
+#include <atomic>
 #include <chrono>
 #include "host_proto.hpp"
 #include "r1cs.cuh"
@@ -544,6 +545,25 @@ int bp_r1cs_prove_scenario(bp_ctx* c, int scenario, const uint64_t* params, cons
     memcpy(commit_xy, io.commitments.data(), io.commitments.size() * 64); *m_out = io.commitments.size();
     memcpy(publics, io.publics.data(), io.publics.size() * 32); *npub = io.publics.size();
     return BP_OK;
+}
+
+// ---- R1CS verify / batch verify (scenario-level drivers) ------------------------------------------------
+int bp_r1cs_verify_scenario(bp_ctx* c, int scenario, const uint64_t* params, const uint8_t* proof, size_t proof_len, const uint64_t* commit_xy, size_t m,
+                            const uint64_t* publics, size_t npub) {
+    if (!c || !params || !proof || (m && !commit_xy) || (npub && !publics)) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->gens_cap) { g_err = "verify: generators not installed"; return BP_E_GENS_LENGTH; }
+    return c->curve == 0 ? verify_scenario<Secq>(c, scenario, params, proof, proof_len, commit_xy, m, publics, npub)
+                         : verify_scenario<Zorro>(c, scenario, params, proof, proof_len, commit_xy, m, publics, npub);
+}
+int bp_r1cs_batch_verify_scenarios(bp_ctx* c, size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs, const size_t* proof_lens,
+                                   const uint64_t* commit_xy, const size_t* ms, const uint64_t* publics, const size_t* npubs, const uint8_t alpha_seed[32],
+                                   double* timing) {
+    if (!c || !count || !scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !npubs || !alpha_seed) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; return BP_E_GENS_LENGTH; }
+    return c->curve == 0 ? batch_verify_scenarios<Secq>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing)
+                         : batch_verify_scenarios<Zorro>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing);
 }
 
 int bp_ctx_set_profiling(bp_ctx* c, int enabled) { if (!c) return BP_E_ARG; c->profiling = enabled != 0; return BP_OK; }

@@ -112,12 +112,14 @@ k_r1cs_poly_eval(const u32* __restrict__ aL, const u32* __restrict__ aR, const u
     store_fe_dev<F>(Hf + o, fe_mul<F>(yni, gf));
 }
 
-// Verifier scalars.  chal: u_sq[k] then u_inv_sq[k] (resident words, creation order), consts: resident words
-// [allinv, x, a, b, u, one-slot unused]; ypow as above (only the inverse half is used).
+// Verifier scalars.  chal: u_sq[k] (resident words, creation order); consts: resident words
+// [allinv, x, a, b, u, alpha]; ypow as above (only the inverse half is used).
 // g[i] = u_or_1 * (x * y^-i * wR[i] - a * s[i]),  h[i] = u_or_1 * (y^-i * (x*wL[i] + wO[i] - b*s[N-1-i]) - 1)
 // with wL/wR/wO = 0 for i >= n.  s[i] = allinv * prod_{j: bit j of i set} u_sq[k-1-j]  (ipp :302-311),
-// s[N-1-i] = the same product over the clear bits.  Output: canonical integers, ready for the MSM.
-template <class C> __global__ void __launch_bounds__(256)
+// s[N-1-i] = the same product over the clear bits.
+// ACC = false (Verifier::verify, verifier.rs:492-514): g_out/h_out <- canonical integers, ready for the MSM.
+// ACC = true  (batch_verify, verifier.rs:649-664): g_out/h_out (resident form) += alpha * g / h.
+template <class C, bool ACC> __global__ void __launch_bounds__(256)
 k_vfy_scalars(const u32* __restrict__ wL, const u32* __restrict__ wR, const u32* __restrict__ wO, const u32* __restrict__ ypow,
               const u32* __restrict__ chal, const u32* __restrict__ consts, u32 n, u32 n1, u32 N, u32 k, u32* __restrict__ g_out,
               u32* __restrict__ h_out) {
@@ -149,8 +151,20 @@ k_vfy_scalars(const u32* __restrict__ wL, const u32* __restrict__ wR, const u32*
         g = fe_mul<F>(g, u);
         h = fe_mul<F>(h, u);
     }
-    store_fe_canon<F>(g_out + o, g);
-    store_fe_canon<F>(h_out + o, h);
+    if (ACC) {
+        const Fe alpha = load_fe_dev<F>(consts + 40);
+        store_fe_dev<F>(g_out + o, fe_norm(fe_add(load_fe_dev<F>(g_out + o), fe_mul<F>(alpha, g))));
+        store_fe_dev<F>(h_out + o, fe_norm(fe_add(load_fe_dev<F>(h_out + o), fe_mul<F>(alpha, h))));
+    } else {
+        store_fe_canon<F>(g_out + o, g);
+        store_fe_canon<F>(h_out + o, h);
+    }
+}
+// resident form -> canonical integers, in place
+template <class F> __global__ void k_scalars_to_canon(u32* __restrict__ v, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store_fe_canon<F>(v + (size_t)i * 8, load_fe_dev<F>(v + (size_t)i * 8));
 }
 
 }  // namespace arkbp

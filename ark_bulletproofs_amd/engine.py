@@ -251,3 +251,39 @@ def host_sha3_512(msg):
     out = C.create_string_buffer(64)
     lib().bp_host_sha3_512(bytes(msg), C.c_size_t(len(msg)), out)
     return out.raw
+
+
+# ---- verifier ----------------------------------------------------------------------------------------
+def _prm(params):
+    prm = np.zeros(8, dtype=np.uint64)
+    prm[: len(params)] = np.array(params, dtype=np.uint64)
+    return prm
+
+
+def _verify_scenario(self, scenario, params, proof, commitments, publics):
+    """Verifier::verify for a scenario statement; returns the C status (0 = Ok, -4 VerificationError, -6 FormatError, ...)"""
+    cm = np.ascontiguousarray(commitments, dtype=np.uint64).reshape(-1, 8)
+    pb = np.ascontiguousarray(publics, dtype=np.uint64).reshape(-1, 4)
+    return lib().bp_r1cs_verify_scenario(self.ctx, scenario, ptr(_prm(params)), bytes(proof), C.c_size_t(len(proof)), ptr(cm), C.c_size_t(len(cm)),
+                                         ptr(pb), C.c_size_t(len(pb)))
+
+
+def _batch_verify(self, instances, alpha_seed):
+    """batch_verify; instances: list of (scenario, params, proof_bytes, commitments, publics).  Returns (status, timing[4])."""
+    n = len(instances)
+    scen = (C.c_int * n)(*[i[0] for i in instances])
+    prm = np.concatenate([_prm(i[1]) for i in instances])
+    proofs = b"".join(i[2] for i in instances)
+    plens = (C.c_size_t * n)(*[len(i[2]) for i in instances])
+    cms = np.ascontiguousarray(np.concatenate([np.asarray(i[3], dtype=np.uint64).reshape(-1, 8) for i in instances]))
+    ms = (C.c_size_t * n)(*[len(np.asarray(i[3]).reshape(-1, 8)) for i in instances])
+    pubs_l = [np.asarray(i[4], dtype=np.uint64).reshape(-1, 4) for i in instances]
+    pubs = np.ascontiguousarray(np.concatenate(pubs_l + [np.zeros((1, 4), dtype=np.uint64)]))
+    npubs = (C.c_size_t * n)(*[len(p) for p in pubs_l])
+    timing = (C.c_double * 4)()
+    rc = lib().bp_r1cs_batch_verify_scenarios(self.ctx, C.c_size_t(n), scen, ptr(prm), proofs, plens, ptr(cms), ms, ptr(pubs), npubs, bytes(alpha_seed), timing)
+    return rc, list(timing)
+
+
+Engine.verify_scenario = _verify_scenario
+Engine.batch_verify = _batch_verify

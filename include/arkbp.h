@@ -110,12 +110,27 @@ int bp_host_sha3_512(const uint8_t* msg, size_t n, uint8_t out[64]);
 int bp_r1cs_prove_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, const uint8_t seed[32], uint8_t* proof_out, size_t* proof_len,
                            uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, double* timing);
 
+/* ---- r1cs::Verifier::verify / batch_verify ------------------------------------------------------------
+ * bp_r1cs_verify_scenario replaces `Verifier::new` + commits + gadget + `verify(&proof, &pc_gens, &bp_gens)`
+ * (src/r1cs/verifier.rs:252-287, 549-600) for the same scenarios as the prover: returns BP_OK, or
+ * BP_E_VERIFICATION / BP_E_FORMAT / BP_E_GENS_LENGTH exactly where the reference returns the matching R1CSError.
+ * bp_r1cs_batch_verify_scenarios replaces `batch_verify(prng, instances, pc_gens, bp_gens)` (:604-691):
+ * `count` instances with concatenated proofs / commitments / publics, params 8 u64 per instance; the per-proof
+ * alpha is `Fr::rand` of a ChaCha20 rng seeded with alpha_seed.  timing[4] (s): total, host replay, GPU scalar
+ * accumulation, final MSM. */
+int bp_r1cs_verify_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, const uint8_t* proof, size_t proof_len, const uint64_t* commit_xy,
+                            size_t m, const uint64_t* publics, size_t npub);
+int bp_r1cs_batch_verify_scenarios(bp_ctx* ctx, size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs,
+                                   const size_t* proof_lens, const uint64_t* commit_xy, const size_t* ms, const uint64_t* publics,
+                                   const size_t* npubs, const uint8_t alpha_seed[32], double* timing);
+
 /* ---- profiling: HIP-event time of the dominant kernel of the last call, on the ctx stream ---------- */
 #define BP_K_MSM_ACCUM 0   /* bucket accumulation (k_msm_accum) */
 #define BP_K_MSM_TOTAL 1   /* all MSM kernels of the call, first launch to last */
 #define BP_K_IPA_SCALARS 2 /* k_ipa_scalars + k_ipa_ip_finish of one round */
 #define BP_K_IPA_FOLD 3    /* k_ipa_fold_ab + k_ipa_fold_pts of one round */
 #define BP_K_R1CS_POLY 4   /* k_r1cs_poly_t / k_r1cs_poly_eval */
+#define BP_K_VFY_SCALARS 5 /* k_vfy_scalars */
 #define BP_K_COUNT 8
 int bp_ctx_set_profiling(bp_ctx* ctx, int enabled);
 /* accumulated milliseconds and launch count since the last reset */

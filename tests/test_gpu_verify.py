@@ -1,0 +1,110 @@
+"""GPU parity of r1cs::Verifier::verify (src/r1cs/verifier.rs:549-600) and batch_verify (:604-691): the engine
+must accept / reject exactly like the CPU oracle on proofs from either side, including the reference's own
+negative cases (tests/r1cs_secq256k1.rs:342-356, 395-411, 447-475)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = bytes([7]) * 32
+OK, E_VERIFICATION, E_GENS, E_FORMAT = 0, -4, -5, -6
+
+
+@pytest.fixture(scope="module", params=[0, 1], ids=["secq256k1", "zorro"])
+def eng(request):
+    import ark_bulletproofs_amd as A
+
+    e = A.Engine(curve=request.param)
+    e.gens_derive(128)
+    yield e
+    e.close()
+
+
+CASES = [
+    (0, [1]), (0, [2]), (0, [3]), (0, [7]), (0, [24]), (0, [42]),
+    (2, [3, 4, 6, 1, 40, 9]), (2, [3, 4, 6, 1, 40, 10]),
+    (1, [2, 3]), (1, [10, 1000]), (1, [63, (1 << 63) - 5]), (1, [10, 1024]), (1, [32, 1 << 32]),
+    (3, [13, 0]), (3, [100, 0]), (3, [13, 1]), (4, [3, 8, 0]), (4, [3, 8, 1]),
+]
+
+
+@pytest.mark.parametrize("sc,prm", CASES)
+def test_verify_matches_oracle(eng, oracle, sc, prm):
+    O, cv = oracle, eng.curve
+    ref = O.r1cs_prove(cv, sc, prm, SEED, 128, m_cap=128)
+    assert ref.rc == 0
+    rc_ref = O.r1cs_verify(cv, sc, prm, 128, ref.proof, ref.commitments, ref.publics)
+    rc = eng.verify_scenario(sc, prm, ref.proof, ref.commitments, ref.publics)
+    assert (rc == OK) == (rc_ref == 0)
+    if rc_ref != 0:
+        assert rc == E_VERIFICATION
+    # a proof produced by the GPU prover verifies the same way
+    got = eng.prove_scenario(sc, prm, SEED, m_cap=128)
+    assert eng.verify_scenario(sc, prm, got.proof, got.commitments, got.publics) == rc
+
+
+def test_verify_rejects_tampering(eng, oracle):
+    O, cv = oracle, eng.curve
+    sc, prm = 1, [16, 12345]
+    ref = O.r1cs_prove(cv, sc, prm, SEED, 128)
+    assert eng.verify_scenario(sc, prm, ref.proof, ref.commitments, ref.publics) == OK
+    # flipped scalar byte (t_x): still well-formed, must fail the mega-check
+    bad = bytearray(ref.proof)
+    bad[11 * 33] ^= 1
+    assert eng.verify_scenario(sc, prm, bytes(bad), ref.commitments, ref.publics) == E_VERIFICATION
+    # malformed encodings -> FormatError, like R1CSProof::from_bytes
+    assert eng.verify_scenario(sc, prm, ref.proof[:-1], ref.commitments, ref.publics) == E_FORMAT
+    bad = bytearray(ref.proof)
+    bad[32] = 0xC0
+    assert eng.verify_scenario(sc, prm, bytes(bad), ref.commitments, ref.publics) == E_FORMAT
+    # wrong commitment
+    cm = ref.commitments.copy()
+    cm[0] = O.generator(cv)
+    assert eng.verify_scenario(sc, prm, ref.proof, cm, ref.publics) == E_VERIFICATION
+    # identity point where the verifier validates (A_I1): rejected before the MSM
+    bad = bytearray(ref.proof)
+    bad[0:33] = bytes(32) + b"\x40"
+    assert eng.verify_scenario(sc, prm, bytes(bad), ref.commitments, ref.publics) == E_VERIFICATION
+    # statement larger than the installed generators
+    big = O.r1cs_prove(cv, 3, [200, 0], SEED, 256, m_cap=8)
+    assert eng.verify_scenario(3, [200, 0], big.proof, big.commitments, big.publics) == E_GENS
+
+
+def test_batch_range_proof_gadget(eng, oracle):
+    """tests/r1cs_secq256k1.rs:447-475: mixed sizes 16/32/64 in one batch, with the two negative sets"""
+    O, cv = oracle, eng.curve
+
+    def run(vals):
+        inst = []
+        for i, (v, n) in enumerate(vals):
+            pr = O.r1cs_prove(cv, O.SC_RANGE, [n, v], bytes([9 + i]) * 32, 128)
+            assert pr.rc == 0
+            inst.append((O.SC_RANGE, [n, v], pr.proof, pr.commitments, pr.publics))
+        rc_ref = O.batch_verify(cv, inst, 128, bytes([5]) * 32)
+        rc, _ = eng.batch_verify(inst, bytes([5]) * 32)
+        assert (rc == OK) == (rc_ref == 0)
+        return rc
+
+    assert run([(0, 16)]) == OK
+    assert run([(0, 16), (3, 16), ((1 << 16) - 1, 16), (1 << 16, 32)]) == OK
+    assert run([(0, 16), (3, 16), (1 << 16, 16), (1 << 16, 32)]) == E_VERIFICATION
+    assert run([(0, 16), (3, 16), ((1 << 16) - 1, 16), (1 << 16, 32), (1 << 63, 64)]) == OK
+    assert run([(0, 16), (3, 16), ((1 << 16) - 1, 16), (1 << 32, 32), (1 << 63, 64)]) == E_VERIFICATION
+
+
+def test_batch_mixed_scenarios_and_many(eng, oracle):
+    O, cv = oracle, eng.curve
+    inst = []
+    for i in range(12):
+        sc, prm = [(0, [5]), (3, [20, 0]), (1, [8, 200]), (4, [2, 8, 0])][i % 4]
+        pr = eng.prove_scenario(sc, prm, bytes([20 + i]) * 32, m_cap=32)
+        inst.append((sc, prm, pr.proof, pr.commitments, pr.publics))
+    rc, timing = eng.batch_verify(inst, bytes([6]) * 32)
+    assert rc == OK and timing[0] > 0
+    assert O.batch_verify(cv, inst, 128, bytes([6]) * 32) == 0
+    # corrupt one proof in the middle: the whole batch must fail
+    sc, prm, proof, cm, pb = inst[5]
+    bad = bytearray(proof)
+    bad[11 * 33 + 40] ^= 2
+    inst[5] = (sc, prm, bytes(bad), cm, pb)
+    rc, _ = eng.batch_verify(inst, bytes([6]) * 32)
+    assert rc == E_VERIFICATION
