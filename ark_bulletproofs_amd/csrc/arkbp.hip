@@ -530,6 +530,16 @@ int bp_transcript_challenge_scalar(int curve, void* t, const char* label, uint64
     return BP_OK;
 }
 int bp_host_sha3_512(const uint8_t* m, size_t n, uint8_t out[64]) { host::sha3_512(out, m, n); return BP_OK; }
+// sum of `count` affine points on the host: the "point-reduce" after an all-gather of per-GPU partial results
+int bp_host_points_sum(int curve, const uint64_t* pts_xy, size_t count, uint64_t out_xy[8]) {
+    if ((!pts_xy && count) || !out_xy) return BP_E_ARG;
+    A4 r;
+    if (curve == 0) { J4 acc = host::Grp<Secq>::inf(); for (size_t i = 0; i < count; i++) { A4 p; memcpy(p.x.v, pts_xy + 8 * i, 32); memcpy(p.y.v, pts_xy + 8 * i + 4, 32); acc = host::Grp<Secq>::madd(acc, p); } r = host::Grp<Secq>::to_aff(acc); }
+    else if (curve == 1) { J4 acc = host::Grp<Zorro>::inf(); for (size_t i = 0; i < count; i++) { A4 p; memcpy(p.x.v, pts_xy + 8 * i, 32); memcpy(p.y.v, pts_xy + 8 * i + 4, 32); acc = host::Grp<Zorro>::madd(acc, p); } r = host::Grp<Zorro>::to_aff(acc); }
+    else return BP_E_ARG;
+    memcpy(out_xy, r.x.v, 32); memcpy(out_xy + 4, r.y.v, 32);
+    return BP_OK;
+}
 
 // ---- R1CS prove (scenario-level driver) ---------------------------------------------------------------
 int bp_r1cs_prove_scenario(bp_ctx* c, int scenario, const uint64_t* params, const uint8_t seed[32], uint8_t* proof_out, size_t* proof_len,
@@ -558,12 +568,12 @@ int bp_r1cs_verify_scenario(bp_ctx* c, int scenario, const uint64_t* params, con
 }
 int bp_r1cs_batch_verify_scenarios(bp_ctx* c, size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs, const size_t* proof_lens,
                                    const uint64_t* commit_xy, const size_t* ms, const uint64_t* publics, const size_t* npubs, const uint8_t alpha_seed[32],
-                                   double* timing) {
+                                   double* timing, size_t alpha_skip, uint64_t* check_point_xy) {
     if (!c || !count || !scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !npubs || !alpha_seed) return BP_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; return BP_E_GENS_LENGTH; }
-    return c->curve == 0 ? batch_verify_scenarios<Secq>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing)
-                         : batch_verify_scenarios<Zorro>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing);
+    return c->curve == 0 ? batch_verify_scenarios<Secq>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy)
+                         : batch_verify_scenarios<Zorro>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy);
 }
 
 int bp_ctx_set_profiling(bp_ctx* c, int enabled) { if (!c) return BP_E_ARG; c->profiling = enabled != 0; return BP_OK; }

@@ -268,8 +268,9 @@ def _verify_scenario(self, scenario, params, proof, commitments, publics):
                                          ptr(pb), C.c_size_t(len(pb)))
 
 
-def _batch_verify(self, instances, alpha_seed):
-    """batch_verify; instances: list of (scenario, params, proof_bytes, commitments, publics).  Returns (status, timing[4])."""
+def _batch_verify(self, instances, alpha_seed, alpha_skip=0, want_point=False):
+    """batch_verify; instances: list of (scenario, params, proof_bytes, commitments, publics).  Returns (status, timing[4])
+    or (status, timing, check_point) when want_point (proof-sharded multi-GPU use, see parallel.py)."""
     n = len(instances)
     scen = (C.c_int * n)(*[i[0] for i in instances])
     prm = np.concatenate([_prm(i[1]) for i in instances])
@@ -281,9 +282,20 @@ def _batch_verify(self, instances, alpha_seed):
     pubs = np.ascontiguousarray(np.concatenate(pubs_l + [np.zeros((1, 4), dtype=np.uint64)]))
     npubs = (C.c_size_t * n)(*[len(p) for p in pubs_l])
     timing = (C.c_double * 4)()
-    rc = lib().bp_r1cs_batch_verify_scenarios(self.ctx, C.c_size_t(n), scen, ptr(prm), proofs, plens, ptr(cms), ms, ptr(pubs), npubs, bytes(alpha_seed), timing)
+    pt = np.zeros(8, dtype=np.uint64)
+    rc = lib().bp_r1cs_batch_verify_scenarios(self.ctx, C.c_size_t(n), scen, ptr(prm), proofs, plens, ptr(cms), ms, ptr(pubs), npubs, bytes(alpha_seed), timing,
+                                              C.c_size_t(alpha_skip), ptr(pt))
+    if want_point:
+        return rc, list(timing), pt
     return rc, list(timing)
 
 
 Engine.verify_scenario = _verify_scenario
 Engine.batch_verify = _batch_verify
+
+
+def host_points_sum(curve, pts_xy):
+    pts = u64arr(pts_xy, 8)
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib().bp_host_points_sum(curve, ptr(pts), C.c_size_t(len(pts)), ptr(out)), "bp_host_points_sum")
+    return out

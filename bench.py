@@ -82,7 +82,8 @@ def run_msm(args, rank, world, local):
     import torch
 
     import ark_bulletproofs_amd as A
-    from ark_bulletproofs_amd import _lib
+    from ark_bulletproofs_amd import engine as E
+    from ark_bulletproofs_amd import parallel as P
 
     n = args.terms
     eng = A.Engine(curve=args.curve, device=local)
@@ -95,13 +96,8 @@ def run_msm(args, rank, world, local):
     barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        part = eng.msm_dev(db, ds, n)
-        if world > 1:
-            import torch.distributed as dist
-
-            t = torch.from_numpy(part.view(np.int64).copy()).cuda()
-            outs = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(outs, t)  # one 64-byte partial point per rank; summed by the caller
+        # term-sharded MSM: local partial, all-gather of one 64-byte point per rank over RCCL, host point-reduce
+        full = P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device="cuda" if world > 1 else None)
     barrier(world)
     dt = time.perf_counter() - t0
     if world > 1:

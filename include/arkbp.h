@@ -97,6 +97,8 @@ void bp_transcript_challenge_bytes(void* t, const char* label, uint8_t* out, siz
 int bp_transcript_append_point(int curve, void* t, const char* label, const uint64_t xy[8]);
 int bp_transcript_challenge_scalar(int curve, void* t, const char* label, uint64_t out[4]);
 int bp_host_sha3_512(const uint8_t* msg, size_t n, uint8_t out[64]);
+/* group sum of affine points on the host (the point-reduce after an all-gather of per-GPU partials) */
+int bp_host_points_sum(int curve, const uint64_t* pts_xy, size_t count, uint64_t out_xy[8]);
 
 /* ---- r1cs::Prover::prove -------------------------------------------------------------------------
  * Replaces `Prover::new` + commits + gadget + `prove(prng, bp_gens)` (src/r1cs/prover.rs:291-341, 444-831)
@@ -117,12 +119,16 @@ int bp_r1cs_prove_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, co
  * bp_r1cs_batch_verify_scenarios replaces `batch_verify(prng, instances, pc_gens, bp_gens)` (:604-691):
  * `count` instances with concatenated proofs / commitments / publics, params 8 u64 per instance; the per-proof
  * alpha is `Fr::rand` of a ChaCha20 rng seeded with alpha_seed.  timing[4] (s): total, host replay, GPU scalar
- * accumulation, final MSM. */
+ * accumulation, final MSM.  Proof-sharded multi-GPU use: rank r passes its slice of the instances, alpha_skip = number
+ * of instances on lower ranks (their alphas are drawn and discarded), and receives the affine value of ITS mega-check
+ * in check_point_xy (may be NULL); the batch is valid iff the sum of all ranks' points is the identity
+ * (bp_host_points_sum after an all-gather) — by linearity that sum is the reference's single MSM (:685). */
 int bp_r1cs_verify_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, const uint8_t* proof, size_t proof_len, const uint64_t* commit_xy,
                             size_t m, const uint64_t* publics, size_t npub);
 int bp_r1cs_batch_verify_scenarios(bp_ctx* ctx, size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs,
                                    const size_t* proof_lens, const uint64_t* commit_xy, const size_t* ms, const uint64_t* publics,
-                                   const size_t* npubs, const uint8_t alpha_seed[32], double* timing);
+                                   const size_t* npubs, const uint8_t alpha_seed[32], double* timing, size_t alpha_skip,
+                                   uint64_t* check_point_xy);
 
 /* ---- profiling: HIP-event time of the dominant kernel of the last call, on the ctx stream ---------- */
 #define BP_K_MSM_ACCUM 0   /* bucket accumulation (k_msm_accum) */

@@ -108,3 +108,42 @@ def test_batch_mixed_scenarios_and_many(eng, oracle):
     inst[5] = (sc, prm, bytes(bad), cm, pb)
     rc, _ = eng.batch_verify(inst, bytes([6]) * 32)
     assert rc == E_VERIFICATION
+
+
+def test_proof_sharded_batch_points_sum_to_identity(eng, oracle):
+    """whole proofs per GPU; the per-shard mega-check points (with alpha_skip) sum to the identity
+    exactly when the unsharded batch verifies — emulated here on one GPU with two shards."""
+    from ark_bulletproofs_amd import engine as E
+    from ark_bulletproofs_amd.parallel import shard_range
+
+    O, cv = oracle, eng.curve
+    inst = []
+    for i in range(7):
+        sc, prm = [(1, [16, 99 + i]), (3, [20, 0]), (0, [4])][i % 3]
+        pr = eng.prove_scenario(sc, prm, bytes([40 + i]) * 32, m_cap=32)
+        inst.append((sc, prm, pr.proof, pr.commitments, pr.publics))
+    seed = bytes([8]) * 32
+    rc_full, _, pt_full = eng.batch_verify(inst, seed, want_point=True)
+    assert rc_full == OK and not pt_full.any()
+    pts = []
+    for r in range(2):
+        lo, hi = shard_range(len(inst), r, 2)
+        rc, _, pt = eng.batch_verify(inst[lo:hi], seed, alpha_skip=lo, want_point=True)
+        assert rc == OK
+        pts.append(pt)
+    assert not E.host_points_sum(cv, np.stack(pts)).any()
+    # one bad proof: its shard's point is not the identity, and neither is the sum
+    sc, prm, proof, cm, pb = inst[5]
+    bad = bytearray(proof)
+    bad[11 * 33 + 40] ^= 2
+    inst[5] = (sc, prm, bytes(bad), cm, pb)
+    pts = []
+    for r in range(2):
+        lo, hi = shard_range(len(inst), r, 2)
+        rc, _, pt = eng.batch_verify(inst[lo:hi], seed, alpha_skip=lo, want_point=True)
+        pts.append(pt)
+    assert E.host_points_sum(cv, np.stack(pts)).any()
+    # the sharded points equal the unsharded mega-check value (same alphas by position)
+    rc_full, _, pt_full = eng.batch_verify(inst, seed, want_point=True)
+    assert rc_full == E_VERIFICATION
+    assert (E.host_points_sum(cv, np.stack(pts)) == pt_full).all()
