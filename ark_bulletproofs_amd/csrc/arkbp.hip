@@ -34,8 +34,10 @@ const char* bp_last_error(void) { return g_err.c_str(); }
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool owned = true;  // false: a view of another ctx's allocation (shared generator tables)
     int ensure(size_t bytes) {
         if (bytes <= cap) return BP_OK;
+        if (!owned) { g_err = "shared device buffer too small"; return BP_E_ARG; }
         if (p) HIPCHK(hipFree(p));
         p = nullptr; cap = 0;
         size_t want = bytes + bytes / 4 + 256;
@@ -43,7 +45,7 @@ struct DevBuf {
         cap = want;
         return BP_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
     template <class T> T* as() { return (T*)p; }
 };
 
@@ -352,6 +354,26 @@ template <class C> __global__ void k_dbg_point(int op, const u32* p, const u32* 
     store_words8(out + (size_t)i * 16, w); store_words8(out + (size_t)i * 16 + 8, w + 8);
 }
 
+// ---- statements (see include/arkbp.h) ----
+struct bp_stmt {
+    int curve = 0;
+    int scenario = 0;
+    host::Transcript tr;
+    host::ChaChaRng prng;
+    host::StatementIO io;
+    std::unique_ptr<host::ConstraintSystem<Secq>> cs0;
+    std::unique_ptr<host::ConstraintSystem<Zorro>> cs1;
+    bool consumed = false;
+    bp_stmt(int sc, const uint8_t* seed) : scenario(sc), tr(host::scenario_label(sc)), prng(seed) {}
+};
+template <class C> static int stmt_build(bp_stmt* s, std::unique_ptr<host::ConstraintSystem<C>>& cs, const uint64_t* params) {
+    cs.reset(new host::ConstraintSystem<C>());
+    cs->tr = &s->tr; cs->proving = true;
+    host::TP<C>::r1cs_domain_sep(s->tr);
+    host::PedersenGens<C> pc = host::PedersenGens<C>::make_default();
+    return host::scenario_prover<C>(*cs, pc, s->prng, s->scenario, params, s->io);
+}
+
 // ---- C ABI ----------------------------------------------------------------------------------------
 extern "C" {
 
@@ -574,6 +596,53 @@ int bp_r1cs_batch_verify_scenarios(bp_ctx* c, size_t count, const int* scenarios
     if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; return BP_E_GENS_LENGTH; }
     return c->curve == 0 ? batch_verify_scenarios<Secq>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy)
                          : batch_verify_scenarios<Zorro>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy);
+}
+
+// ---- statements: Prover::new + commits + gadget, separated from prove() ----------------------------------
+int bp_stmt_prover_create(int curve, int scenario, const uint64_t* params, const uint8_t seed[32], bp_stmt** out) {
+    if (!params || !seed || !out || (curve != 0 && curve != 1)) return BP_E_ARG;
+    bp_stmt* s = new bp_stmt(scenario, seed);
+    s->curve = curve;
+    int rc = curve == 0 ? stmt_build<Secq>(s, s->cs0, params) : stmt_build<Zorro>(s, s->cs1, params);
+    if (rc) { delete s; return rc; }
+    *out = s;
+    return BP_OK;
+}
+void bp_stmt_free(bp_stmt* s) { delete s; }
+int bp_stmt_info(bp_stmt* s, uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, size_t* multipliers, size_t* constraints) {
+    if (!s || !m_out || !npub) return BP_E_ARG;
+    if (s->io.commitments.size() > m_cap || s->io.publics.size() > 8) return BP_E_ARG;
+    if (commit_xy) memcpy(commit_xy, s->io.commitments.data(), s->io.commitments.size() * 64);
+    if (publics) memcpy(publics, s->io.publics.data(), s->io.publics.size() * 32);
+    *m_out = s->io.commitments.size(); *npub = s->io.publics.size();
+    if (multipliers) *multipliers = s->curve == 0 ? s->cs0->num_vars : s->cs1->num_vars;
+    if (constraints) *constraints = s->curve == 0 ? s->cs0->num_constraints() : s->cs1->num_constraints();
+    return BP_OK;
+}
+int bp_stmt_prove(bp_ctx* c, bp_stmt* s, uint8_t* proof_out, size_t* proof_len, double* timing) {
+    if (!c || !s || !proof_out || !proof_len || s->curve != c->curve) return BP_E_ARG;
+    if (s->consumed) { g_err = "bp_stmt_prove: statement already consumed (Prover::prove takes self)"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->gens_cap) { g_err = "prove: generators not installed (bp_gens_derive / bp_gens_upload / bp_gens_share)"; return BP_E_GENS_LENGTH; }
+    s->consumed = true;
+    host::ProofData pf;
+    StageTimes tm;
+    int rc = c->curve == 0 ? r1cs_prove<Secq>(c, *s->cs0, s->prng, pf, tm) : r1cs_prove<Zorro>(c, *s->cs1, s->prng, pf, tm);
+    if (rc) return rc;
+    std::vector<host::u8> bytes = c->curve == 0 ? host::proof_to_bytes<Secq>(pf) : host::proof_to_bytes<Zorro>(pf);
+    if (bytes.size() > *proof_len) { g_err = "prove: output buffer too small"; return BP_E_ARG; }
+    memcpy(proof_out, bytes.data(), bytes.size()); *proof_len = bytes.size();
+    if (timing) { timing[0] = tm.total; timing[1] = 0; timing[2] = tm.rng; timing[3] = tm.upload; timing[4] = tm.commit_msm; timing[5] = tm.flatten; timing[6] = tm.poly; timing[7] = tm.ipa; }
+    return BP_OK;
+}
+// dst uses src's resident generator tables (same device, same curve) without copying; src must outlive dst
+int bp_gens_share(bp_ctx* dst, bp_ctx* src) {
+    if (!dst || !src || dst == src || dst->curve != src->curve || dst->device != src->device || !src->gens_cap) return BP_E_ARG;
+    DevBuf* d[] = {&dst->d_G, &dst->d_H, &dst->d_pc};
+    DevBuf* sr[] = {&src->d_G, &src->d_H, &src->d_pc};
+    for (int i = 0; i < 3; i++) { d[i]->release(); d[i]->p = sr[i]->p; d[i]->cap = sr[i]->cap; d[i]->owned = false; }
+    dst->gens_cap = src->gens_cap; dst->pc_B = src->pc_B; dst->pc_Bb = src->pc_Bb;
+    return BP_OK;
 }
 
 int bp_ctx_set_profiling(bp_ctx* c, int enabled) { if (!c) return BP_E_ARG; c->profiling = enabled != 0; return BP_OK; }

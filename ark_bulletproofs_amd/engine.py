@@ -299,3 +299,47 @@ def host_points_sum(curve, pts_xy):
     out = np.zeros(8, dtype=np.uint64)
     check(lib().bp_host_points_sum(curve, ptr(pts), C.c_size_t(len(pts)), ptr(out)), "bp_host_points_sum")
     return out
+
+
+# ---- statements (setup separated from prove(), several proofs in flight) -----------------------------------
+class Statement:
+    """Prover::new + commits + gadget for a scenario (host only).  prove(engine) consumes it."""
+
+    def __init__(self, curve, scenario, params, seed):
+        self.h = C.c_void_p()
+        check(lib().bp_stmt_prover_create(curve, scenario, ptr(_prm(params)), bytes(seed), C.byref(self.h)), "bp_stmt_prover_create")
+        self.curve = curve
+
+    def info(self, m_cap=1 << 16):
+        commits = np.zeros((m_cap, 8), dtype=np.uint64)
+        pubs = np.zeros((8, 4), dtype=np.uint64)
+        m, npub, nm, nq = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        check(lib().bp_stmt_info(self.h, ptr(commits), C.c_size_t(m_cap), C.byref(m), ptr(pubs), C.byref(npub), C.byref(nm), C.byref(nq)), "bp_stmt_info")
+        return commits[: m.value].copy(), pubs[: npub.value].copy(), nm.value, nq.value
+
+    def prove(self, eng):
+        buf = C.create_string_buffer(1 << 16)
+        plen = C.c_size_t(len(buf))
+        timing = (C.c_double * 8)()
+        check(lib().bp_stmt_prove(eng.ctx, self.h, buf, C.byref(plen), timing), "bp_stmt_prove")
+        return buf.raw[: plen.value], list(timing)
+
+    def free(self):
+        if self.h:
+            lib().bp_stmt_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _share_gens_from(self, other):
+    check(lib().bp_gens_share(self.ctx, other.ctx), "bp_gens_share")
+    self.gens_capacity = getattr(other, "gens_capacity", 0)
+    self._gens_owner = other  # keep the owner alive
+
+
+Engine.share_gens_from = _share_gens_from

@@ -112,6 +112,19 @@ int bp_host_points_sum(int curve, const uint64_t* pts_xy, size_t count, uint64_t
 int bp_r1cs_prove_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, const uint8_t seed[32], uint8_t* proof_out, size_t* proof_len,
                            uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, double* timing);
 
+/* Statement handles: `Prover::new` + `commit`s + gadget (src/r1cs/prover.rs:291-341; host only, no GPU) separated from
+ * `prove()` so that a service can keep several proofs in flight: the per-proof TranscriptRng chain (8 Keccak-f per
+ * multiplier, strictly sequential inside one proof) of one statement overlaps the GPU work of the others.  Each in-flight
+ * proof uses its own bp_ctx (stream + workspaces); bp_gens_share lets them all read one resident copy of the tables.
+ * bp_stmt_prove consumes the statement (`prove(self, ..)`); timing as in bp_r1cs_prove_scenario ([1] = 0). */
+typedef struct bp_stmt bp_stmt;
+int bp_stmt_prover_create(int curve, int scenario, const uint64_t* params, const uint8_t seed[32], bp_stmt** out);
+void bp_stmt_free(bp_stmt* stmt);
+int bp_stmt_info(bp_stmt* stmt, uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, size_t* multipliers,
+                 size_t* constraints);
+int bp_stmt_prove(bp_ctx* ctx, bp_stmt* stmt, uint8_t* proof_out, size_t* proof_len, double* timing);
+int bp_gens_share(bp_ctx* dst, bp_ctx* src);
+
 /* ---- r1cs::Verifier::verify / batch_verify ------------------------------------------------------------
  * bp_r1cs_verify_scenario replaces `Verifier::new` + commits + gadget + `verify(&proof, &pc_gens, &bp_gens)`
  * (src/r1cs/verifier.rs:252-287, 549-600) for the same scenarios as the prover: returns BP_OK, or

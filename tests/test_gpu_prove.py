@@ -52,3 +52,38 @@ def test_prove_needs_enough_generators(eng):
     with pytest.raises(A.ArkbpError) as ei:
         eng.prove_scenario(3, [200, 0], SEED)  # 200 multipliers -> padded 256 > capacity 128
     assert ei.value.code == -5  # InvalidGeneratorsLength
+
+
+def test_statement_api_and_concurrent_proofs(eng, oracle):
+    """bp_stmt_*: setup separated from prove(); several proofs in flight on one GPU (own ctx + host thread each, shared
+    resident generator tables) must still be byte-identical to the oracle's proofs."""
+    import threading
+
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+
+    O, cv = oracle, eng.curve
+    cases = [(3, [100, 0]), (0, [24]), (1, [32, 77]), (4, [3, 8, 0]), (3, [64, 0]), (0, [7])]
+    engs = [A.Engine(curve=cv) for _ in cases]
+    for e in engs:
+        e.share_gens_from(eng)
+    stmts = [E.Statement(cv, sc, prm, bytes([50 + i]) * 32) for i, (sc, prm) in enumerate(cases)]
+    cm0, pb0, nm, nq = stmts[0].info()
+    assert nm == 100 and nq == 201 and len(cm0) == 1
+    out = [None] * len(cases)
+
+    def work(k):
+        out[k] = stmts[k].prove(engs[k])
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(cases))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i, (sc, prm) in enumerate(cases):
+        ref = O.r1cs_prove(cv, sc, prm, bytes([50 + i]) * 32, 128, m_cap=128)
+        assert out[i] is not None and out[i][0] == ref.proof
+    with pytest.raises(A.ArkbpError):  # Prover::prove consumes self
+        stmts[0].prove(engs[0])
+    for e in engs:
+        e.close()
