@@ -219,6 +219,22 @@ template <class C> static int msm_dev_entry(bp_ctx* ctx, const void* d_bases, co
 typedef std::function<int(const uint64_t* L_xy, const uint64_t* R_xy, uint64_t* u_out)> ChallengeFn;
 
 template <class F> static Words8 words_of(const F4& x) { Words8 w; memcpy(w.w, x.v, 32); return w; }
+// non-adjacent form of the canonical value of x: sum_i (plus_i - minus_i) 2^i, no two adjacent non-zero digits
+template <class S> static Naf naf_of(const F4& x) {
+    Naf r; memset(&r, 0, sizeof r);
+    uint64_t k[5] = {0, 0, 0, 0, 0};
+    S::to_canon(k, x);
+    for (int i = 0; i < 258; i++) {
+        if (!(k[0] | k[1] | k[2] | k[3] | k[4])) break;
+        if (k[0] & 1) {
+            if ((k[0] & 3) == 1) { r.plus[i >> 5] |= 1u << (i & 31); k[0] &= ~(uint64_t)1; }
+            else { r.minus[i >> 5] |= 1u << (i & 31); for (int j = 0; j < 5; j++) { if (++k[j]) break; } }  // k += 1
+        }
+        for (int j = 0; j < 4; j++) k[j] = (k[j] >> 1) | (k[j + 1] << 63);
+        k[4] >>= 1;
+    }
+    return r;
+}
 
 template <class C>
 static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b, size_t n,
@@ -232,6 +248,9 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
     BPCHK(ctx->ipa_part.ensure(((n / 2 + 255) / 256 + 1) * 64));
     bool first = true;
     size_t round = 0;
+    // pending common factors of the resident generator vectors: G_true = gamma_G * Ghat, H_true = gamma_H * Hhat
+    F4 gamma_G = S::one(), gamma_H = S::one();
+    bool pending = false;
     while (n != 1) {
         n /= 2;
         const u32 gb = (u32)((n + 255) / 256);
@@ -239,7 +258,8 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
         u32* sR = ctx->ipa_sR.as<u32>();
         {
             ScopedK tk(ctx, BP_K_IPA_SCALARS);
-            hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, d_Gf, d_Hf, first ? 1 : 0, (u32)n, sL, sR, ctx->ipa_part.as<u32>());
+            hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, d_Gf, d_Hf, first ? 1 : 0, (u32)n, sL, sR, ctx->ipa_part.as<u32>(),
+                               pending ? 1 : 0, words_of<S>(gamma_G), words_of<S>(gamma_H));
             hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8);
         }
         BaseSegs sg; memset(&sg, 0, sizeof sg);
@@ -261,8 +281,16 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
         {
             ScopedK tk(ctx, BP_K_IPA_FOLD);
             hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
-            hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, first ? 1 : 0, (u32)n, words_of<S>(u),
-                               words_of<S>(ui));
+            if (first) {
+                hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u),
+                                   words_of<S>(ui));
+            } else {
+                // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
+                Naf tG = naf_of<S>(S::sqr(ui)), tH = naf_of<S>(S::sqr(u));
+                hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tH);
+                gamma_G = S::mul(gamma_G, u); gamma_H = S::mul(gamma_H, ui);
+                pending = true;
+            }
         }
         HIPCHK(hipGetLastError());
         first = false;

@@ -75,10 +75,14 @@ template <class F> __global__ void k_scalars_export(const u32* __restrict__ in, 
     store_words8(out + (size_t)i * 8, w);
 }
 
+struct Words8 {
+    u32 w[8];
+};
+
 // n = half length.  sL/sR: (2n+1) x 8 words each (canonical integers).  partials: gridDim.x x 2 x 8 words.
 template <class C> __global__ void __launch_bounds__(256)
 k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ Gf, const u32* __restrict__ Hf, int first, u32 n,
-              u32* __restrict__ sL, u32* __restrict__ sR, u32* __restrict__ partials) {
+              u32* __restrict__ sL, u32* __restrict__ sR, u32* __restrict__ partials, int pending, Words8 gGw, Words8 gHw) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,6 +98,11 @@ k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* _
             yl = fe_mul<F>(bR, load_fe_dev<F>(Hf + (size_t)i * 8));
             xr = fe_mul<F>(aR, load_fe_dev<F>(Gf + (size_t)i * 8));
             yr = fe_mul<F>(bL, load_fe_dev<F>(Hf + (size_t)(n + i) * 8));
+        }
+        if (pending) {  // the resident G/H hold Ghat = G / gamma_G, Hhat = H / gamma_H (see k_ipa_fold_uniform)
+            const Fe gG = fe_load_ark<F>(gGw.w), gH = fe_load_ark<F>(gHw.w);
+            xl = fe_mul<F>(xl, gG); xr = fe_mul<F>(xr, gG);
+            yl = fe_mul<F>(yl, gH); yr = fe_mul<F>(yr, gH);
         }
         store_fe_canon<F>(sL + (size_t)i * 8, xl);
         store_fe_canon<F>(sL + (size_t)(n + i) * 8, yl);
@@ -123,10 +132,6 @@ k_ipa_ip_finish(const u32* __restrict__ partials, u32 nparts, u32* __restrict__ 
         store_fe_canon<F>(outR, pr);
     }
 }
-
-struct Words8 {
-    u32 w[8];
-};
 
 // u, u_inv: ark Montgomery words
 template <class C> __global__ void __launch_bounds__(256)
@@ -184,6 +189,42 @@ k_ipa_fold_pts(u32* __restrict__ G, u32* __restrict__ H, const u32* __restrict__
     const Aff P1 = load_aff_dev(V + (size_t)i * 16), P2 = load_aff_dev(V + (size_t)(n + i) * 16);
     const Jac r = shamir2<C>(P1, P2, s1, s2);
     const Aff o = jac_to_aff<C>(r);
+    u32 w[16];
+    aff_store_dev(w, o);
+    store_words8(V + (size_t)i * 16, w);
+    store_words8(V + (size_t)i * 16 + 8, w + 8);
+}
+
+// Uniform-scalar rounds (every round after the first; src/inner_product_proof.rs:219-224).  With the same (u^-1, u) for all
+// i,  u^-1*G_L[i] + u*G_R[i] = u * (G_R[i] + u^-2 * G_L[i]):  the lane computes only Ghat'[i] = G_R[i] + t*G_L[i] (ONE scalar
+// multiplication, t = u^-2 for G, u^2 for H) and the common factor is kept as a pending scalar gamma that k_ipa_scalars
+// multiplies into the next rounds' MSM scalars — G and H themselves are never output by the prover.  t is wave-uniform, so its
+// non-adjacent form is computed once on the host: bit i of plus/minus = digit +1/-1 at 2^i (257 digits).
+struct Naf {
+    u32 plus[9], minus[9];
+};
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf tH) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const bool isH = t >= n;  // n is a multiple of 64 or the grid is a single partial wave: waves are homogeneous for n >= 64
+    const u32 i = isH ? t - n : t;
+    u32* V = isH ? H : G;
+    const Aff P1 = load_aff_dev(V + (size_t)i * 16), P2 = load_aff_dev(V + (size_t)(n + i) * 16);
+    const Aff N1 = aff_cneg_lazy<C>(P1, true);
+    Jac acc = jac_inf<C>();
+#pragma unroll 1
+    for (int wd = 8; wd >= 0; wd--) {
+        const u32 ep = isH ? tH.plus[wd] : tG.plus[wd], em = isH ? tH.minus[wd] : tG.minus[wd];
+#pragma unroll 1
+        for (int bit = (wd == 8 ? 0 : 31); bit >= 0; bit--) {
+            acc = jac_dbl<C>(acc);
+            if ((ep >> bit) & 1) acc = jac_madd<C>(acc, P1);
+            else if ((em >> bit) & 1) acc = jac_madd<C>(acc, N1);
+        }
+    }
+    acc = jac_madd<C>(acc, P2);
+    const Aff o = jac_to_aff<C>(acc);
     u32 w[16];
     aff_store_dev(w, o);
     store_words8(V + (size_t)i * 16, w);
