@@ -238,7 +238,8 @@ template <class S> static Naf naf_of(const F4& x) {
 
 template <class C>
 static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b, size_t n,
-                          const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4]) {
+                          const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4],
+                          const F4* gf_halves = nullptr /* optional hint: G_factors == gf_halves[0] on [0,n/2) and gf_halves[1] on [n/2,n) */) {
     typedef host::Fld<typename C::Fr> S;
     typedef host::Grp<C> G;
     if (n == 0 || (n & (n - 1))) { g_err = "ipa_create: n must be a power of two (reference asserts, src/inner_product_proof.rs:66)"; return BP_E_ARG; }
@@ -281,13 +282,21 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
         {
             ScopedK tk(ctx, BP_K_IPA_FOLD);
             hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
-            if (first) {
+            if (first && gf_halves && !gf_halves[0].is_zero() && !gf_halves[1].is_zero()) {
+                // G: u^-1*gL*G_L + u*gR*G_R = (u*gR) * (G_R + t*G_L), t = u^-1*gL / (u*gR): uniform, one NAF ladder; H: per-lane factors
+                const F4 s2 = S::mul(u, gf_halves[1]);
+                Naf tG = naf_of<S>(S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)));
+                hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tG, 1);
+                hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u), words_of<S>(ui), 2);
+                gamma_G = S::mul(gamma_G, s2);
+                pending = true;
+            } else if (first) {
                 hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u),
-                                   words_of<S>(ui));
+                                   words_of<S>(ui), 3);
             } else {
                 // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
                 Naf tG = naf_of<S>(S::sqr(ui)), tH = naf_of<S>(S::sqr(u));
-                hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tH);
+                hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tH, 3);
                 gamma_G = S::mul(gamma_G, u); gamma_H = S::mul(gamma_H, ui);
                 pending = true;
             }

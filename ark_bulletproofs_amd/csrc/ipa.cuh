@@ -146,9 +146,12 @@ k_ipa_fold_ab(u32* __restrict__ a, u32* __restrict__ b, u32 n, Words8 uw, Words8
     store_fe_dev<F>(b + (size_t)i * 8, fe_norm(fe_add(fe_mul<F>(bL, ui), fe_mul<F>(u, bR))));
 }
 
-// joint double-and-add: s1*P1 + s2*P2 with canonical 256-bit s1, s2 (lane-private or wave-uniform)
+// joint double-and-add: s1*P1 + s2*P2 with lane-private canonical 256-bit s1, s2.  Lanes disagree on which of
+// {P1, P2, P1+P2} to add at each step, so the addend is SELECTED (predicated moves over a 3-entry Jacobian table) and one
+// general addition runs for the whole wave; branching per lane would serialise three different add shapes.
 template <class C> __device__ __forceinline__ Jac shamir2(const Aff& P1, const Aff& P2, const u32 s1[8], const u32 s2[8]) {
-    const Jac T3 = jac_madd<C>(jac_from_aff<C>(P1), P2);
+    const Jac T1 = jac_from_aff<C>(P1), T2 = jac_from_aff<C>(P2);
+    const Jac T3 = jac_madd<C>(T1, P2);
     Jac acc = jac_inf<C>();
 #pragma unroll 1
     for (int wd = 7; wd >= 0; wd--) {
@@ -156,10 +159,22 @@ template <class C> __device__ __forceinline__ Jac shamir2(const Aff& P1, const A
 #pragma unroll 1
         for (int bit = 31; bit >= 0; bit--) {
             acc = jac_dbl<C>(acc);
-            const u32 sel = ((e1 >> bit) & 1) | (((e2 >> bit) & 1) << 1);
-            if (sel == 1) acc = jac_madd<C>(acc, P1);
-            else if (sel == 2) acc = jac_madd<C>(acc, P2);
-            else if (sel == 3) acc = jac_add<C>(acc, T3);
+            const u32 b1 = (e1 >> bit) & 1, b2 = (e2 >> bit) & 1;
+            Jac t;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                t.X.l[i] = b2 ? (b1 ? T3.X.l[i] : T2.X.l[i]) : T1.X.l[i];
+                t.Y.l[i] = b2 ? (b1 ? T3.Y.l[i] : T2.Y.l[i]) : T1.Y.l[i];
+                t.Z.l[i] = b2 ? (b1 ? T3.Z.l[i] : T2.Z.l[i]) : T1.Z.l[i];
+            }
+            const Jac r = jac_add<C>(acc, t);
+            const bool take = (b1 | b2) != 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                acc.X.l[i] = take ? r.X.l[i] : acc.X.l[i];
+                acc.Y.l[i] = take ? r.Y.l[i] : acc.Y.l[i];
+                acc.Z.l[i] = take ? r.Z.l[i] : acc.Z.l[i];
+            }
         }
     }
     return acc;
@@ -169,12 +184,12 @@ template <class C> __device__ __forceinline__ Jac shamir2(const Aff& P1, const A
 // u, u_inv ark Montgomery words.  In place: lane i reads elements i and n+i of its vector, writes i.
 template <class C> __global__ void __launch_bounds__(256)
 k_ipa_fold_pts(u32* __restrict__ G, u32* __restrict__ H, const u32* __restrict__ Gf, const u32* __restrict__ Hf, int first, u32 n, Words8 uw,
-               Words8 uiw) {
+               Words8 uiw, int which /* 1: G only, 2: H only, 3: both */) {
     typedef typename C::Fr F;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * n) return;
-    const bool isH = t >= n;
-    const u32 i = isH ? t - n : t;
+    if (t >= (which == 3 ? 2 * n : n)) return;
+    const bool isH = which == 2 || (which == 3 && t >= n);
+    const u32 i = (which == 3 && isH) ? t - n : t;
     u32* V = isH ? H : G;
     const u32* Vf = isH ? Hf : Gf;
     // G: (u^-1 * Gf[i], u * Gf[n+i])      H: (u * Hf[i], u^-1 * Hf[n+i])
@@ -204,11 +219,11 @@ struct Naf {
     u32 plus[9], minus[9];
 };
 template <class C> __global__ void __launch_bounds__(256)
-k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf tH) {
+k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf tH, int which /* 1: G only, 2: H only, 3: both */) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * n) return;
-    const bool isH = t >= n;  // n is a multiple of 64 or the grid is a single partial wave: waves are homogeneous for n >= 64
-    const u32 i = isH ? t - n : t;
+    if (t >= (which == 3 ? 2 * n : n)) return;
+    const bool isH = which == 2 || (which == 3 && t >= n);  // waves are homogeneous for n >= 64
+    const u32 i = (which == 3 && isH) ? t - n : t;
     u32* V = isH ? H : G;
     const Aff P1 = load_aff_dev(V + (size_t)i * 16), P2 = load_aff_dev(V + (size_t)(n + i) * 16);
     const Aff N1 = aff_cneg_lazy<C>(P1, true);
