@@ -391,6 +391,41 @@ template <class C> __global__ void k_dbg_point(int op, const u32* p, const u32* 
     store_words8(out + (size_t)i * 16, w); store_words8(out + (size_t)i * 16 + 8, w + 8);
 }
 
+template <class C> static int dbg_rng_draws(void* transcript, const uint64_t* witness, size_t nw, const uint8_t* seeds, int lanes, size_t count, uint64_t* out) {
+    typedef typename C::Fr FrP; typedef host::Fld<FrP> S;
+    std::vector<std::unique_ptr<host::TranscriptRng>> rngs;
+    for (int j = 0; j < lanes; j++) {
+        rngs.emplace_back(new host::TranscriptRng(*(host::Transcript*)transcript));
+        for (size_t i = 0; i < nw; i++) { F4 w; memcpy(w.v, witness + 4 * i, 32); host::u8 b[32]; S::to_bytes(b, w); rngs[j]->rekey("v_blinding", b, 32); }
+        host::ChaChaRng ext(seeds + 32 * j);
+        rngs[j]->finalize(ext);
+    }
+    if (lanes == 1) { for (size_t i = 0; i < count; i++) { F4 x = host::rand_fe<FrP>(*rngs[0]); memcpy(out + 4 * i, x.v, 32); } return BP_OK; }
+#if defined(__x86_64__)
+    if (lanes != 8 || !host::cpu_has_avx512() || count < 3) return BP_E_ARG;
+    host::TranscriptRng* rp[8];
+    for (int j = 0; j < 8; j++) {
+        for (size_t i = 0; i < 3; i++) { F4 x = host::rand_fe<FrP>(*rngs[j]); memcpy(out + 4 * (j * count + i), x.v, 32); }
+        rp[j] = rngs[j].get();
+        if (rp[j]->s.pos != 8 || rp[j]->s.pos_begin != 0) return BP_E_ARG;
+    }
+    std::vector<u64> words((count - 3) * 4 * 8);
+    host::transcript_rng_x8_words(rp, words.data(), (count - 3) * 4);
+    for (int j = 0; j < 8; j++)
+        for (size_t i = 3; i < count; i++)
+            for (int w = 0; w < 4; w++) {
+                u64 x = words[(4 * (i - 3) + w) * 8 + j];
+                if (w == 3 && FrP::BITS < 256) x &= (~(u64)0) >> (256 - FrP::BITS);  // Fp::rand masks the top limb
+                out[4 * (j * count + i) + w] = x;
+            }
+    // the scalar continuation from the x8 state must also agree: one more draw each, returned in place of the last one
+    for (int j = 0; j < 8; j++) { F4 x = host::rand_fe<FrP>(*rngs[j]); (void)x; }
+    return BP_OK;
+#else
+    return BP_E_ARG;
+#endif
+}
+
 // ---- statements (see include/arkbp.h) ----
 struct bp_stmt {
     int curve = 0;
@@ -400,6 +435,8 @@ struct bp_stmt {
     host::StatementIO io;
     std::unique_ptr<host::ConstraintSystem<Secq>> cs0;
     std::unique_ptr<host::ConstraintSystem<Zorro>> cs1;
+    ProvePre<Secq> pre0;
+    ProvePre<Zorro> pre1;
     bool consumed = false;
     bp_stmt(int sc, const uint8_t* seed) : scenario(sc), tr(host::scenario_label(sc)), prng(seed) {}
 };
@@ -589,6 +626,14 @@ int bp_transcript_challenge_scalar(int curve, void* t, const char* label, uint64
     return BP_OK;
 }
 int bp_host_sha3_512(const uint8_t* m, size_t n, uint8_t out[64]) { host::sha3_512(out, m, n); return BP_OK; }
+// test hook (host only): the prover's TranscriptRng (build_rng, rekey "v_blinding" per witness scalar, finalize with
+// ChaCha20(seed)), then `count` Fr::rand draws.  lanes = 1: scalar path; lanes = 8: eight rngs (seeds[8][32]) advanced by the
+// AVX-512 x8 stream after 3 scalar draws each, out = 8 x count scalars.  Returns BP_E_ARG when lanes = 8 is unavailable.
+int bp_debug_rng_draws(int curve, void* transcript, const uint64_t* witness, size_t nw, const uint8_t* seeds, int lanes, size_t count, uint64_t* out) {
+    if (!transcript || !seeds || !out || (nw && !witness)) return BP_E_ARG;
+    return curve == 0 ? dbg_rng_draws<Secq>(transcript, witness, nw, seeds, lanes, count, out)
+         : curve == 1 ? dbg_rng_draws<Zorro>(transcript, witness, nw, seeds, lanes, count, out) : BP_E_ARG;
+}
 // sum of `count` affine points on the host: the "point-reduce" after an all-gather of per-GPU partial results
 int bp_host_points_sum(int curve, const uint64_t* pts_xy, size_t count, uint64_t out_xy[8]) {
     if ((!pts_xy && count) || !out_xy) return BP_E_ARG;
@@ -664,12 +709,38 @@ int bp_stmt_prove(bp_ctx* c, bp_stmt* s, uint8_t* proof_out, size_t* proof_len, 
     s->consumed = true;
     host::ProofData pf;
     StageTimes tm;
-    int rc = c->curve == 0 ? r1cs_prove<Secq>(c, *s->cs0, s->prng, pf, tm) : r1cs_prove<Zorro>(c, *s->cs1, s->prng, pf, tm);
+    int rc = c->curve == 0 ? r1cs_prove<Secq>(c, *s->cs0, s->prng, pf, tm, &s->pre0) : r1cs_prove<Zorro>(c, *s->cs1, s->prng, pf, tm, &s->pre1);
     if (rc) return rc;
     std::vector<host::u8> bytes = c->curve == 0 ? host::proof_to_bytes<Secq>(pf) : host::proof_to_bytes<Zorro>(pf);
     if (bytes.size() > *proof_len) { g_err = "prove: output buffer too small"; return BP_E_ARG; }
     memcpy(proof_out, bytes.data(), bytes.size()); *proof_len = bytes.size();
     if (timing) { timing[0] = tm.total; timing[1] = 0; timing[2] = tm.rng; timing[3] = tm.upload; timing[4] = tm.commit_msm; timing[5] = tm.flatten; timing[6] = tm.poly; timing[7] = tm.ipa; }
+    return BP_OK;
+}
+// host-only head of prove(): `m`, TranscriptRng, phase-1 blinding draws (the sequential Keccak chain); idempotent
+int bp_stmt_precompute(bp_stmt* s) {
+    if (!s || s->consumed) return BP_E_ARG;
+    if (s->curve == 0) { if (!s->pre0.rng) prove_precompute<Secq>(*s->cs0, s->prng, s->pre0); }
+    else { if (!s->pre1.rng) prove_precompute<Zorro>(*s->cs1, s->prng, s->pre1); }
+    return BP_OK;
+}
+// the same for a batch: groups of 8 same-shaped statements share one AVX-512 Keccak-f x8 stream; others go one by one
+int bp_stmt_precompute_batch(bp_stmt** stmts, size_t count) {
+    if (!stmts) return BP_E_ARG;
+    for (size_t i = 0; i < count; i++) if (!stmts[i] || stmts[i]->consumed || stmts[i]->curve != stmts[0]->curve) return BP_E_ARG;
+    for (size_t g = 0; g < count; g += 8) {
+        const size_t c = std::min<size_t>(8, count - g);
+        host::ChaChaRng* prngs[8];
+        if (stmts[0]->curve == 0) {
+            host::ConstraintSystem<Secq>* css[8]; ProvePre<Secq>* pres[8];
+            for (size_t j = 0; j < c; j++) { css[j] = stmts[g + j]->cs0.get(); prngs[j] = &stmts[g + j]->prng; pres[j] = &stmts[g + j]->pre0; }
+            prove_precompute_batch<Secq>(css, prngs, pres, c);
+        } else {
+            host::ConstraintSystem<Zorro>* css[8]; ProvePre<Zorro>* pres[8];
+            for (size_t j = 0; j < c; j++) { css[j] = stmts[g + j]->cs1.get(); prngs[j] = &stmts[g + j]->prng; pres[j] = &stmts[g + j]->pre1; }
+            prove_precompute_batch<Zorro>(css, prngs, pres, c);
+        }
+    }
     return BP_OK;
 }
 // dst uses src's resident generator tables (same device, same curve) without copying; src must outlive dst

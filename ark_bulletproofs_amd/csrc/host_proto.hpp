@@ -108,9 +108,55 @@ struct TranscriptRng {
         s.meta_ad((const u8*)label, strlen(label), false); s.meta_ad((const u8*)&len, 4, true); s.key(w, n, false);
     }
     template <class R> void finalize(R& ext) { u8 b[32]; ext.fill_bytes(b, 32); s.meta_ad((const u8*)"rng", 3, false); s.key(b, 32, false); }
-    inline u64 next_u64() { u32 len = 8; u64 x; s.meta_ad((const u8*)&len, 4, false); s.prf((u8*)&x, 8, false); return x; }
+    // fill_bytes(8).  Steady state (pos = 8, pos_begin = 0, i.e. right after a previous 8-byte draw): the six STROBE steps
+    // meta_ad(LE32(8)) ; prf(8) collapse to three constant XORs, one permutation and reading lane 0.
+    inline u64 next_u64() {
+        if (s.pos == 8 && s.pos_begin == 0) {
+            s.st.w[1] ^= 0x0709000000081200ULL;  // bytes 8..15: [0,M|A] [8,0,0,0] [9,I|A|C]
+            s.st.w[2] ^= 0x040FULL;              // run_f: st[16] ^= pos_begin (15), st[17] ^= 0x04
+            s.st.w[20] ^= 0x8000000000000000ULL; //        st[R+1 = 167] ^= 0x80
+            keccakf(s.st.w);
+            const u64 x = s.st.w[0];
+            s.st.w[0] = 0;                       // squeeze zeroes what it reads; pos = 8, pos_begin = 0 again
+            s.cur = Strobe::fI | Strobe::fA | Strobe::fC;
+            return x;
+        }
+        u32 len = 8; u64 x; s.meta_ad((const u8*)&len, 4, false); s.prf((u8*)&x, 8, false); return x;
+    }
     inline u32 next_u32() { u32 len = 4; u32 x; s.meta_ad((const u8*)&len, 4, false); s.prf((u8*)&x, 4, false); return x; }
 };
+
+// Eight independent TranscriptRngs advanced in lockstep, one per 64-bit lane of AVX-512 registers (Keccak-f x8 needs no
+// cross-lane traffic).  All eight must be in the steady state above; their word streams are exactly what eight separate
+// next_u64() sequences would produce.  out[t * 8 + j] = word t of instance j.
+static inline bool cpu_has_avx512() {
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx512f");
+#else
+    return false;
+#endif
+}
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) static inline void transcript_rng_x8_words(TranscriptRng* const rngs[8], u64* out, size_t nwords) {
+    alignas(64) u64 lanes[25][8];
+    for (int i = 0; i < 25; i++) for (int j = 0; j < 8; j++) lanes[i][j] = rngs[j]->s.st.w[i];
+    __m512i st[25];
+    for (int i = 0; i < 25; i++) st[i] = _mm512_load_si512((const void*)lanes[i]);
+    const __m512i k1 = _mm512_set1_epi64((long long)0x0709000000081200ULL), k2 = _mm512_set1_epi64(0x040FLL),
+                  k20 = _mm512_set1_epi64((long long)0x8000000000000000ULL);
+    for (size_t t = 0; t < nwords; t++) {
+        st[1] = _mm512_xor_si512(st[1], k1);
+        st[2] = _mm512_xor_si512(st[2], k2);
+        st[20] = _mm512_xor_si512(st[20], k20);
+        keccakf_x8_avx512(st);
+        _mm512_storeu_si512((void*)(out + t * 8), st[0]);
+        st[0] = _mm512_setzero_si512();
+    }
+    for (int i = 0; i < 25; i++) _mm512_store_si512((void*)lanes[i], st[i]);
+    for (int i = 0; i < 25; i++) for (int j = 0; j < 8; j++) rngs[j]->s.st.w[i] = lanes[i][j];
+    for (int j = 0; j < 8; j++) rngs[j]->s.cur = Strobe::fI | Strobe::fA | Strobe::fC;
+}
+#endif
 
 // ark-ff Fp::rand: raw limbs (top limb masked to the modulus width) accepted iff < p; they ARE the Montgomery form
 template <class P, class R> static inline F4 rand_fe(R& rng) {

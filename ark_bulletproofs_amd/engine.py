@@ -235,6 +235,18 @@ class HostTranscript:
         return out
 
 
+def debug_rng_draws(curve, transcript, witness, seeds, count):
+    """seeds: one 32-byte seed (scalar path) or eight (AVX-512 x8 path); returns (lanes, count, 4) u64 or None if unavailable"""
+    w = np.ascontiguousarray(witness, dtype=np.uint64).reshape(-1, 4)
+    lanes = len(seeds) // 32
+    out = np.zeros((lanes, count, 4), dtype=np.uint64)
+    rc = lib().bp_debug_rng_draws(curve, transcript.h, ptr(w), C.c_size_t(len(w)), bytes(seeds), lanes, C.c_size_t(count), ptr(out))
+    if rc == _lib.BP_E_ARG and lanes == 8:
+        return None
+    check(rc, "bp_debug_rng_draws")
+    return out
+
+
 def pedersen_gens(curve):
     B, Bb = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
     check(lib().bp_pedersen_gens(curve, ptr(B), ptr(Bb)), "bp_pedersen_gens")
@@ -317,6 +329,10 @@ class Statement:
         check(lib().bp_stmt_info(self.h, ptr(commits), C.c_size_t(m_cap), C.byref(m), ptr(pubs), C.byref(npub), C.byref(nm), C.byref(nq)), "bp_stmt_info")
         return commits[: m.value].copy(), pubs[: npub.value].copy(), nm.value, nq.value
 
+    def precompute(self):
+        """host-only head of prove(): the TranscriptRng chain (needs no GPU)"""
+        check(lib().bp_stmt_precompute(self.h), "bp_stmt_precompute")
+
     def prove(self, eng):
         buf = C.create_string_buffer(1 << 16)
         plen = C.c_size_t(len(buf))
@@ -343,3 +359,9 @@ def _share_gens_from(self, other):
 
 
 Engine.share_gens_from = _share_gens_from
+
+
+def precompute_batch(stmts):
+    """host-only head of prove() for many statements; groups of 8 same-shaped ones share one AVX-512 Keccak-f x8 stream"""
+    arr = (C.c_void_p * len(stmts))(*[s.h for s in stmts])
+    check(lib().bp_stmt_precompute_batch(arr, C.c_size_t(len(stmts))), "bp_stmt_precompute_batch")

@@ -152,33 +152,74 @@ def run_prove(args, rank, world, local):
     for e in engs[1:]:
         e.share_gens_from(engs[0])
 
-    def make_statements(step):
-        return [E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], bytes([3 + step, 1 + k] + [3] * 30)) for k in range(P)]
+    def make_statements(tag, count):
+        out = [None] * count
 
-    def run_batch(stmts, out):
-        def work(k):
-            out[k] = stmts[k].prove(engs[k])
+        def mk(k):
+            out[k] = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], bytes([3 + tag, 1 + (k & 0xFF), k >> 8] + [3] * 29))
 
-        th = [threading.Thread(target=work, args=(k,)) for k in range(P)]
+        th = [threading.Thread(target=mk, args=(k,)) for k in range(count)]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        return out
 
-    for w in range(args.warmup):
-        out = [None] * P
-        run_batch(make_statements(100 + w), out)
+    def run_pool(stmts, out):
+        """Two stages, all inside the timed region.  Stage 1 (host pool): the head of prove() — TranscriptRng chain, 8
+        sequential Keccak-f per multiplier — for statements in order.  Stage 2 (P GPU drivers, one ctx/stream each): the rest
+        of prove().  The chain of proof k+1 overlaps the GPU work of proof k."""
+        import queue
+
+        ready = queue.Queue()
+        lock = threading.Lock()
+        nxt = [0]
+
+        def stage1():
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 8
+                if i >= len(stmts):
+                    return
+                grp = list(range(i, min(i + 8, len(stmts))))
+                E.precompute_batch([stmts[g] for g in grp])   # 8 chains in lockstep in AVX-512 lanes (Keccak-f x8)
+                for g in grp:
+                    ready.put(g)
+
+        def stage2(k):
+            while True:
+                i = ready.get()
+                if i is None:
+                    return
+                out[i] = stmts[i].prove(engs[k])
+
+        t1 = [threading.Thread(target=stage1) for _ in range(args.host_threads)]
+        t2 = [threading.Thread(target=stage2, args=(k,)) for k in range(P)]
+        for t in t1 + t2:
+            t.start()
+        for t in t1:
+            t.join()
+        for _ in t2:
+            ready.put(None)
+        for t in t2:
+            t.join()
+
+    if args.warmup:
+        ws = make_statements(100, args.batch * args.warmup)
+        run_pool(ws, [None] * len(ws))
+        del ws
     for e in engs:
         e.set_profiling(True)
         e.reset_profiling()
-    batches = [make_statements(s) for s in range(args.steps)]   # untimed: inputs prepared before the timed region
-    results = [[None] * P for _ in range(args.steps)]
+    stmts = make_statements(0, args.batch * args.steps)   # untimed: statements (commits + gadget) exist before the timed region
+    flat = [None] * len(stmts)
     barrier(world)
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        run_batch(batches[s], results[s])
+    run_pool(stmts, flat)                        # K steps x P proofs
     barrier(world)
     dt = time.perf_counter() - t0
+    results = [flat]
     if world > 1:
         import torch.distributed as dist
 
@@ -189,7 +230,7 @@ def run_prove(args, rank, world, local):
     for r in results:
         for (_, tm) in r:
             stages += np.array(tm)
-    nproofs = P * args.steps
+    nproofs = args.batch * args.steps
     fold_ms = sum(e.kernel_time(3)[0] for e in engs)
     fold_n = sum(e.kernel_time(3)[1] for e in engs)
     acc_ms = sum(e.kernel_time(0)[0] for e in engs)
@@ -199,9 +240,9 @@ def run_prove(args, rank, world, local):
         "metric": "r1cs_constraints_proved_per_sec", "value": N * world * nproofs / dt, "unit": "constraints/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
-        "config": {"workload": "cfg3: 2^%d-constraint R1CS prove (square-chain circuit, m=1, q=2N+1), %s, %d independent proofs in flight per GPU per step"
-                               % (args.logn, ["secq256k1", "zorro"][args.curve], P),
-                   "constraints_per_proof": N, "proofs_in_flight": P, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": "replicas x%d" % world,
+        "config": {"workload": "cfg3: 2^%d-constraint R1CS prove (square-chain circuit, m=1, q=2N+1), %s, a step = %d independent proofs per GPU (%d GPU streams, %d host threads for the TranscriptRng stage)"
+                               % (args.logn, ["secq256k1", "zorro"][args.curve], args.batch, P, args.host_threads),
+                   "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": "replicas x%d" % world,
                    "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
@@ -253,7 +294,9 @@ def main():
     ap.add_argument("--workload", default="prove", choices=["prove", "msm"])
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=13)
-    ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
+    ap.add_argument("--batch", type=int, default=16, help="independent proofs per step per GPU (prove workload)")
+    ap.add_argument("--host-threads", type=int, default=4, help="host threads running the TranscriptRng head of prove()")
+    ap.add_argument("--inflight", type=int, default=6, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--terms", type=int, default=1 << 16)
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -97,6 +97,10 @@ void bp_transcript_challenge_bytes(void* t, const char* label, uint8_t* out, siz
 int bp_transcript_append_point(int curve, void* t, const char* label, const uint64_t xy[8]);
 int bp_transcript_challenge_scalar(int curve, void* t, const char* label, uint64_t out[4]);
 int bp_host_sha3_512(const uint8_t* msg, size_t n, uint8_t out[64]);
+/* test hook, host only: the prover's TranscriptRng (src/r1cs/prover.rs:483-494) then `count` Fr::rand draws; lanes = 1 scalar
+ * path (one 32-byte seed), lanes = 8 the AVX-512 x8 stream (8 seeds; out = 8 x count scalars; BP_E_ARG if unavailable) */
+int bp_debug_rng_draws(int curve, void* transcript, const uint64_t* witness, size_t nw, const uint8_t* seeds, int lanes, size_t count,
+                       uint64_t* out);
 /* group sum of affine points on the host (the point-reduce after an all-gather of per-GPU partials) */
 int bp_host_points_sum(int curve, const uint64_t* pts_xy, size_t count, uint64_t out_xy[8]);
 
@@ -122,6 +126,12 @@ int bp_stmt_prover_create(int curve, int scenario, const uint64_t* params, const
 void bp_stmt_free(bp_stmt* stmt);
 int bp_stmt_info(bp_stmt* stmt, uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, size_t* multipliers,
                  size_t* constraints);
+/* Optional, host only (no ctx): runs the head of prove() — `m`, TranscriptRng construction and the phase-1 blinding draws
+ * (src/r1cs/prover.rs:466-513) — so it can overlap other proofs' GPU work; bp_stmt_prove continues from that state. */
+int bp_stmt_precompute(bp_stmt* stmt);
+/* Batch form: statements of the same curve; every group of 8 with equal multiplier / commitment counts advances its eight
+ * TranscriptRng chains in lockstep in AVX-512 lanes (Keccak-f x8), producing exactly the per-statement streams. */
+int bp_stmt_precompute_batch(bp_stmt** stmts, size_t count);
 int bp_stmt_prove(bp_ctx* ctx, bp_stmt* stmt, uint8_t* proof_out, size_t* proof_len, double* timing);
 int bp_gens_share(bp_ctx* dst, bp_ctx* src);
 

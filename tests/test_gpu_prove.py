@@ -87,3 +87,20 @@ def test_statement_api_and_concurrent_proofs(eng, oracle):
         stmts[0].prove(engs[0])
     for e in engs:
         e.close()
+
+
+def test_batched_precompute_x8(eng, oracle):
+    """bp_stmt_precompute_batch: 8 same-shaped statements share one AVX-512 Keccak-f x8 stream for their TranscriptRng
+    chains; the proofs must still be byte-identical to the oracle's (which runs plain scalar merlin)."""
+    from ark_bulletproofs_amd import engine as E
+
+    O, cv = oracle, eng.curve
+    sc, prm = 3, [100, 0]
+    stmts = [E.Statement(cv, sc, prm, bytes([70 + i]) * 32) for i in range(8)]
+    odd = E.Statement(cv, 1, [16, 5], bytes([90]) * 32)          # different shape: takes the scalar path
+    E.precompute_batch(stmts + [odd])
+    for i, st in enumerate(stmts):
+        proof, _ = st.prove(eng)
+        assert proof == O.r1cs_prove(cv, sc, prm, bytes([70 + i]) * 32, 128, m_cap=8).proof
+    proof, _ = odd.prove(eng)
+    assert proof == O.r1cs_prove(cv, 1, [16, 5], bytes([90]) * 32, 128).proof

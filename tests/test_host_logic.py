@@ -60,3 +60,25 @@ def test_product_generators_match_oracle(E, oracle, curve):
     assert (E.host_derive_generators(curve, 1, 0, n) == Ho).all()
     g1, _ = O.bp_gens_party(curve, 8, 3)
     assert (E.host_derive_generators(curve, 0, 3, 8) == g1).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_product_transcript_rng_scalar_and_x8(E, oracle, curve):
+    """The prover's blinding stream: product scalar path (with the collapsed steady-state STROBE step) and the AVX-512
+    Keccak-f x8 lockstep path must both equal the oracle's plain merlin TranscriptRng, draw for draw."""
+    O = oracle
+    FR = O.fid(curve, True)
+    wit = O.fe_rand(FR, bytes([77]) * 32, 3)
+    count = 40
+    tp, to = E.HostTranscript(b"rngtest"), O.Transcript(b"rngtest")
+    tp.append_message(b"x", b"abc")
+    to.append_message(b"x", b"abc")
+    seeds = [bytes([10 + j]) * 32 for j in range(8)]
+    ref = [O.Transcript(handle=None, label=b"unused") if False else None for _ in range(8)]
+    exp = np.stack([to.rng_draws(curve, wit, seeds[j], count) for j in range(8)])
+    got1 = E.debug_rng_draws(curve, tp, wit, seeds[0], count)
+    assert (got1[0] == exp[0]).all()
+    got8 = E.debug_rng_draws(curve, tp, wit, b"".join(seeds), count)
+    if got8 is None:
+        pytest.skip("no AVX-512 on this host: the x8 path is not taken")
+    assert (got8 == exp).all()
