@@ -263,6 +263,83 @@ def run_prove(args, rank, world, local):
     return res
 
 
+def run_verify(args, rank, world, local):
+    """cfg4: batch verification of `--proofs` R1CS proofs with 2^14 constraints each (256 x 64-bit range proofs in one
+    circuit, m = 256: n = 16384, q = 33024).  The instance list is built from `--distinct` distinct proofs (proved on the GPU
+    before the timed region) repeated round-robin; every instance is replayed, alpha-scaled and accumulated separately.
+    A step = one batch_verify call per rank over its shard of whole proofs; ranks exchange one 64-byte check point."""
+    import torch
+
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+    from ark_bulletproofs_amd import parallel as P
+
+    nval, nbits = 256, 64
+    N = nval * nbits
+    eng = A.Engine(curve=args.curve, device=local)
+    eng.gens_derive(N)
+    distinct = []
+    for i in range(args.distinct):
+        pr = eng.prove_scenario(E.SC_MULTI_RANGE, [nval, nbits, 0], bytes([4, i & 0xFF, i >> 8] + [4] * 29), m_cap=nval + 8)
+        distinct.append((E.SC_MULTI_RANGE, [nval, nbits, 0], pr.proof, pr.commitments, pr.publics))
+    total = args.proofs * world
+    lo, hi = P.shard_range(total, rank, world)
+    inst = [distinct[i % len(distinct)] for i in range(lo, hi)]
+    seed = bytes([5]) * 32
+    for _ in range(args.warmup):
+        eng.batch_verify(inst[: max(8, len(inst) // 8)], seed)
+    eng.set_profiling(True)
+    eng.reset_profiling()
+    barrier(world)
+    t0 = time.perf_counter()
+    tms = np.zeros(4)
+    ok = True
+    for _ in range(args.steps):
+        rc, tm, pt = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
+        parts = P.allgather_points(pt, device="cuda" if world > 1 else None)
+        ok = ok and rc == 0 and not E.host_points_sum(args.curve, parts).any()
+        tms += np.array(tm)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0].item())
+    assert ok, "batch verification of valid proofs failed"
+    k = 14
+    per_proof_bytes = 352 * N + 96 * (13 + nval + 2 * k)
+    vs_ms, vs_n = eng.kernel_time(5)
+    res = {
+        "metric": "r1cs_batch_verifies_per_sec", "value": total * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
+        "config": {"workload": "cfg4: batch_verify of %d R1CS proofs per GPU, 2^14 constraints each (256 x 64-bit range proofs, m=256), %s"
+                               % (args.proofs, ["secq256k1", "zorro"][args.curve]),
+                   "proofs_per_gpu": args.proofs, "distinct_proofs": len(distinct), "constraints_per_proof": N, "parallelism": "proof-sharded x%d" % world,
+                   "stage_ms_per_step": {"total": tms[0] / args.steps * 1e3, "host_replay": tms[1] / args.steps * 1e3,
+                                         "gpu_scalar_accumulation": tms[2] / args.steps * 1e3, "final_msm": tms[3] / args.steps * 1e3}},
+    }
+    if vs_n:
+        avg_s = vs_ms / vs_n * 1e-3
+        # k_vfy_scalars per launch (one proof): reads wL, wR, wO (96*N B), read-modify-writes the shared g/h accumulators (128*N B)
+        res["roofline"] = {"bound": "hbm", "kernel": "k_vfy_scalars<ACC> (one proof per launch)", "achieved": 224.0 * N / avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": 224.0 * N / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": vs_ms / vs_n,
+                           "algorithmic_bytes_per_verify": per_proof_bytes}
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import pyoracle as O
+
+        m = min(8, len(distinct))
+        tim = []
+        rc = O.batch_verify(args.curve, distinct[:m], N, seed, timing=tim)
+        assert rc == 0
+        res["cpu_baseline"] = {"value": m / tim[0], "unit": "proofs/s", "cores": 1, "kind": "port",
+                               "sample": "batch_verify of %d of the same proofs (%.1f s), reference algorithm restated in C++" % (m, tim[0])}
+    eng.close()
+    return res
+
+
 def cpu_baseline_prove(args):
     """CPU restatement of the reference prover (oracle/protocol.hpp: per-element 2-term msm + into_affine in the
     folds, ark window schedule), 1 thread, bounded sample of the same circuit family."""
@@ -289,20 +366,22 @@ def cpu_baseline_msm(args, bases, sc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="prove", choices=["prove", "msm"])
+    ap.add_argument("--workload", default="prove", choices=["prove", "verify", "msm"])
+    ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=13)
     ap.add_argument("--batch", type=int, default=16, help="independent proofs per step per GPU (prove workload)")
-    ap.add_argument("--host-threads", type=int, default=4, help="host threads running the TranscriptRng head of prove()")
-    ap.add_argument("--inflight", type=int, default=6, help="independent proofs in flight per GPU (prove workload)")
+    ap.add_argument("--host-threads", type=int, default=3, help="host threads running the TranscriptRng head of prove()")
+    ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--terms", type=int, default=1 << 16)
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     rank, world, local = dist_setup(args.gpus)
-    res = run_msm(args, rank, world, local) if args.workload == "msm" else run_prove(args, rank, world, local)
+    res = {"msm": run_msm, "prove": run_prove, "verify": run_verify}[args.workload](args, rank, world, local)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
