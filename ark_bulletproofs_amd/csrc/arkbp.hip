@@ -62,7 +62,7 @@ struct bp_ctx {
     KTimer timers[BP_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // MSM workspaces
-    DevBuf canon, hist, lvl_off, totals, cursor, entries, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
+    DevBuf canon, hist, lvl_off, totals, cursor, entries, slots, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
     // IPA workspaces (resident layouts)
     DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q;
     // generator tables (BulletproofGens party 0, PedersenGens), resident layout
@@ -132,9 +132,8 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     BPCHK(ctx->canon.ensure(n * 32));
     BPCHK(ctx->hist.ensure(pl.B * 4));
     BPCHK(ctx->lvl_off.ensure(Bp1 * NL * 4));
-    BPCHK(ctx->totals.ensure((NL + 1) * 4 + (size_t)ntiles * (NL + 1) * 4));
+    BPCHK(ctx->totals.ensure((NL + 2) * 4 + (size_t)ntiles * (NL + 1) * 4));
     BPCHK(ctx->cursor.ensure(pl.B * 4));
-    BPCHK(ctx->entries.ensure(n * pl.W * 4));
     BPCHK(ctx->Tbuf.ensure((size_t)pl.W * pl.c * 96));
     if (!ctx->h_totals) HIPCHK(hipHostMalloc((void**)&ctx->h_totals, 64));
     const size_t tbytes = (size_t)pl.W * pl.c * 96;
@@ -143,22 +142,45 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         HIPCHK(hipHostMalloc((void**)&ctx->h_T, tbytes + 4096));
         ctx->h_T_cap = tbytes + 4096;
     }
+    // slot plan of the one-pass sort
+    SlotPlan sp; memset(&sp, 0, sizeof sp);
+    size_t nslots = 0;
+    if (pl.W > MSM_MAXW) { g_err = "msm: too many windows"; return BP_E_ARG; }
+    for (int w = 0; w < pl.W; w++) {
+        const int bits_left = C::Fr::BITS - pl.c * w;  // scalar bits at or above this window's base
+        size_t nb_eff = (size_t)pl.NB;
+        if (bits_left < pl.c - 1) nb_eff = std::min<size_t>(nb_eff, ((size_t)1 << std::max(bits_left, 0)) + 1);
+        size_t cap = std::min<size_t>(n, 2 * ((n + nb_eff - 1) / nb_eff) + 32);
+        sp.base[w] = (u32)nslots; sp.cap[w] = (u32)cap;
+        nslots += nb_eff * cap;
+    }
+    if (nslots >= ((size_t)1 << 32)) { g_err = "msm: slot array too large"; return BP_E_ARG; }
+    BPCHK(ctx->slots.ensure(nslots * 4));
     ScopedK total(ctx, BP_K_MSM_TOTAL);
     u32* lvl = ctx->lvl_off.as<u32>();
     u32* d_tot = ctx->totals.as<u32>();
-    u32* d_tiles = d_tot + (NL + 1);
+    u32* d_tiles = d_tot + (NL + 2);
+    u32* d_over = d_tot + (NL + 1);
     HIPCHK(hipMemsetAsync(ctx->hist.p, 0, pl.B * 4, st));
+    HIPCHK(hipMemsetAsync(d_over, 0, 4, st));
     const int TB = 256;
     const u32 gb = (u32)((n + TB - 1) / TB);
-    hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont);
+    hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont, sp,
+                       ctx->slots.as<u32>(), d_over);
     hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl);
-    HIPCHK(hipMemcpyAsync(ctx->cursor.p, lvl, pl.B * 4, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 1) * 4, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(k_msm_scatter, dim3(gb), dim3(TB), 0, st, ctx->canon.as<u32>(), ctx->cursor.as<u32>(), ctx->entries.as<u32>(), pl);
+    HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
+    const bool slotted = ctx->h_totals[NL + 1] == 0;
+    const u32* entries_ptr = ctx->slots.as<u32>();
+    if (!slotted) {  // some bucket outgrew its slots (skewed scalars): exact counting-sort scatter
+        BPCHK(ctx->entries.ensure(n * pl.W * 4));
+        HIPCHK(hipMemcpyAsync(ctx->cursor.p, lvl, pl.B * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_msm_scatter, dim3(gb), dim3(TB), 0, st, ctx->canon.as<u32>(), ctx->cursor.as<u32>(), ctx->entries.as<u32>(), pl);
+        entries_ptr = ctx->entries.as<u32>();
+    }
     const u32* tot = ctx->h_totals;
     const u32 maxcnt = tot[NL];
     if (tot[0] == 0) { total.stop(); return BP_OK; }  // every digit zero: the identity
@@ -170,8 +192,8 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (K >= 2) BPCHK(ctx->lvB.ensure((size_t)tot[2] * 96));
     {
         ScopedK acc(ctx, BP_K_MSM_ACCUM);
-        hipLaunchKernelGGL(k_msm_accum<C>, dim3((tot[1] + TB - 1) / TB), dim3(TB), 0, st, segs, ctx->entries.as<u32>(), lvl, lvl + Bp1,
-                           ctx->lvA.as<u32>(), pl.B, tot[1]);
+        hipLaunchKernelGGL(k_msm_accum<C>, dim3((tot[1] + TB - 1) / TB), dim3(TB), 0, st, segs, entries_ptr, lvl, lvl + Bp1, ctx->lvA.as<u32>(), pl.B,
+                           tot[1], slotted ? 1 : 0, sp, (u32)pl.NB);
     }
     u32* cur = ctx->lvA.as<u32>();
     u32* nxt = ctx->lvB.as<u32>();
@@ -475,7 +497,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
+    DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q,
                       &c->d_G, &c->d_H, &c->d_pc, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
                       &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail};

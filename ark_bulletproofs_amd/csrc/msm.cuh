@@ -47,6 +47,15 @@ struct MsmPlan {
     u32 n;
 };
 
+// One-pass sort: bucket (w, v) owns the fixed slot range [base[w] + v*cap[w], +cap[w]) so the histogram pass can place
+// entries directly; cap[w] is ~2x the expected population (windows with few possible digit values get wider slots).  A bucket
+// that outgrows its slots raises `overflow` and the exact two-pass path (k_msm_scatter) is used for that MSM instead.
+static constexpr int MSM_MAXW = 88;
+struct SlotPlan {
+    u32 base[MSM_MAXW];
+    u32 cap[MSM_MAXW];
+};
+
 __device__ __forceinline__ void load_words8(u32 w[8], const u32* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1];
@@ -122,7 +131,8 @@ __device__ __forceinline__ u32 wave_count(u32* __restrict__ ctr, u32 key, bool v
 
 // 1. digits + histogram.  scalars_mont: 0 canonical integers, 1 ark Montgomery words, 2 resident layout.
 template <class C> __global__ void __launch_bounds__(256)
-k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont) {
+k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont, SlotPlan sp,
+             u32* __restrict__ slots, u32* __restrict__ overflow) {
     typedef typename C::Fr Fr;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < pl.n;
@@ -143,7 +153,13 @@ k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __re
     u32 carry = 0;
     for (int w = 0; w < pl.W; w++) {
         const int d = msm_digit(k, w, pl.c, carry);
-        (void)wave_count(hist, (u32)w * pl.NB + (u32)(d < 0 ? -d : d) - 1, live && d != 0);
+        const bool valid = live && d != 0;
+        const u32 v = (u32)(d < 0 ? -d : d) - 1;
+        const u32 pos = wave_count(hist, (u32)w * pl.NB + v, valid);
+        if (valid) {
+            if (pos < sp.cap[w]) slots[sp.base[w] + v * sp.cap[w] + pos] = (i << 1) | (d < 0 ? 1u : 0u);
+            else *overflow = 1u;
+        }
     }
 }
 
@@ -253,12 +269,20 @@ __device__ __forceinline__ u32 find_bucket(const u32* __restrict__ off, u32 B, u
 // 4. level 1: lane j sums the j-th CH-entry chunk (mixed adds of gathered affine bases)
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restrict__ off0, const u32* __restrict__ off1, u32* __restrict__ out,
-            u32 B, u32 nchunks) {
+            u32 B, u32 nchunks, int slotted, SlotPlan sp, u32 NB) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nchunks) return;
     const u32 b = find_bucket(off1, B, j);
-    const u32 beg = off0[b] + (j - off1[b]) * MSM_CH;
-    const u32 end = min(beg + MSM_CH, off0[b + 1]);
+    u32 beg, end;
+    if (slotted) {  // entries = slot array; the bucket's population is off0[b+1] - off0[b]
+        const u32 w = b / NB, v = b - w * NB;
+        const u32 s0 = sp.base[w] + v * sp.cap[w];
+        beg = s0 + (j - off1[b]) * MSM_CH;
+        end = min(beg + MSM_CH, s0 + (off0[b + 1] - off0[b]));
+    } else {
+        beg = off0[b] + (j - off1[b]) * MSM_CH;
+        end = min(beg + MSM_CH, off0[b + 1]);
+    }
     Jac acc = jac_inf<C>();
     for (u32 e = beg; e < end; e++) {
         const u32 ent = entries[e];
