@@ -261,7 +261,10 @@ template <class S> static Naf naf_of(const F4& x) {
 template <class C>
 static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b, size_t n,
                           const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4],
-                          const F4* gf_halves = nullptr /* optional hint: G_factors == gf_halves[0] on [0,n/2) and gf_halves[1] on [n/2,n) */) {
+                          const F4* gf_halves = nullptr /* optional hint: G_factors == gf_halves[0] on [0,n/2) and gf_halves[1] on [n/2,n) */,
+                          const F4* rho_pw = nullptr /* optional hint (with gf_halves): H_factors[i] = rho^i * G_factors[i];
+                                                        rho_pw[k] = rho^-(2^k), rho_pw[32+k] = rho^(2^k), k < 32 */,
+                          const u32* d_rho_pow = nullptr /* device table of rho^(2^k), resident words */) {
     typedef host::Fld<typename C::Fr> S;
     typedef host::Grp<C> G;
     if (n == 0 || (n & (n - 1))) { g_err = "ipa_create: n must be a power of two (reference asserts, src/inner_product_proof.rs:66)"; return BP_E_ARG; }
@@ -273,7 +276,8 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
     size_t round = 0;
     // pending common factors of the resident generator vectors: G_true = gamma_G * Ghat, H_true = gamma_H * Hhat
     F4 gamma_G = S::one(), gamma_H = S::one();
-    bool pending = false;
+    bool pending = false, h_geo = false;  // h_geo: H_true[i] = gamma_H * rho^i * Hhat[i]
+    auto lg2 = [](size_t x) { int k = 0; while (((size_t)1 << k) < x) k++; return k; };
     while (n != 1) {
         n /= 2;
         const u32 gb = (u32)((n + 255) / 256);
@@ -282,7 +286,7 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
         {
             ScopedK tk(ctx, BP_K_IPA_SCALARS);
             hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, d_Gf, d_Hf, first ? 1 : 0, (u32)n, sL, sR, ctx->ipa_part.as<u32>(),
-                               pending ? 1 : 0, words_of<S>(gamma_G), words_of<S>(gamma_H));
+                               pending ? (h_geo ? 2 : 1) : 0, words_of<S>(gamma_G), words_of<S>(gamma_H), d_rho_pow);
             hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8);
         }
         BaseSegs sg; memset(&sg, 0, sizeof sg);
@@ -304,7 +308,19 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
         {
             ScopedK tk(ctx, BP_K_IPA_FOLD);
             hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
-            if (first && gf_halves && !gf_halves[0].is_zero() && !gf_halves[1].is_zero()) {
+            if (first && gf_halves && rho_pw && d_rho_pow && !gf_halves[0].is_zero() && !gf_halves[1].is_zero()) {
+                // both halves uniform.  G as below.  H: u*gL*rho^i*H_L + u^-1*gR*rho^(n+i)*H_R = (u^-1*gR*rho^n) * rho^i * (H_R + t*H_L),
+                // t = u^2 * (gL/gR) * rho^-n: the pending factor of H stays geometric, K * rho^i.
+                const int k = lg2(n);
+                const F4 s2 = S::mul(u, gf_halves[1]);
+                const F4 ginv = S::inv(gf_halves[1]);
+                Naf tG = naf_of<S>(S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)));
+                Naf tH = naf_of<S>(S::mul(S::mul(S::sqr(u), S::mul(gf_halves[0], ginv)), rho_pw[k]));
+                hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tH, 3);
+                gamma_G = S::mul(gamma_G, s2);
+                gamma_H = S::mul(S::mul(ui, gf_halves[1]), rho_pw[32 + k]);
+                pending = true; h_geo = true;
+            } else if (first && gf_halves && !gf_halves[0].is_zero() && !gf_halves[1].is_zero()) {
                 // G: u^-1*gL*G_L + u*gR*G_R = (u*gR) * (G_R + t*G_L), t = u^-1*gL / (u*gR): uniform, one NAF ladder; H: per-lane factors
                 const F4 s2 = S::mul(u, gf_halves[1]);
                 Naf tG = naf_of<S>(S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)));
@@ -317,9 +333,13 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                                    words_of<S>(ui), 3);
             } else {
                 // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
-                Naf tG = naf_of<S>(S::sqr(ui)), tH = naf_of<S>(S::sqr(u));
+                // (geometric pending factor: c[i]/c[n+i] = rho^-n joins t, and K picks up rho^n)
+                const int k = lg2(n);
+                Naf tG = naf_of<S>(S::sqr(ui));
+                Naf tH = naf_of<S>(h_geo ? S::mul(S::sqr(u), rho_pw[k]) : S::sqr(u));
                 hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tH, 3);
-                gamma_G = S::mul(gamma_G, u); gamma_H = S::mul(gamma_H, ui);
+                gamma_G = S::mul(gamma_G, u);
+                gamma_H = h_geo ? S::mul(S::mul(gamma_H, ui), rho_pw[32 + k]) : S::mul(gamma_H, ui);
                 pending = true;
             }
         }

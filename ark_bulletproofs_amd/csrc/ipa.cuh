@@ -78,11 +78,20 @@ template <class F> __global__ void k_scalars_export(const u32* __restrict__ in, 
 struct Words8 {
     u32 w[8];
 };
+// x^e from a table of x^(2^k) (resident words), e < 2^32
+template <class F> __device__ __forceinline__ Fe pow_table(const u32* __restrict__ tab, u32 e) {
+    Fe r = fe_one<F>();
+#pragma unroll 1
+    for (int k = 0; e; k++, e >>= 1)
+        if (e & 1) r = fe_mul<F>(r, load_fe_dev<F>(tab + (size_t)k * 8));
+    return r;
+}
 
 // n = half length.  sL/sR: (2n+1) x 8 words each (canonical integers).  partials: gridDim.x x 2 x 8 words.
 template <class C> __global__ void __launch_bounds__(256)
 k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ Gf, const u32* __restrict__ Hf, int first, u32 n,
-              u32* __restrict__ sL, u32* __restrict__ sR, u32* __restrict__ partials, int pending, Words8 gGw, Words8 gHw) {
+              u32* __restrict__ sL, u32* __restrict__ sR, u32* __restrict__ partials, int pending, Words8 gGw, Words8 gHw,
+              const u32* __restrict__ rho_pow /* pending == 2: H_true[i] = K * rho^i * Hhat[i], K = gHw, table of rho^(2^k) */) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,7 +111,13 @@ k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* _
         if (pending) {  // the resident G/H hold Ghat = G / gamma_G, Hhat = H / gamma_H (see k_ipa_fold_uniform)
             const Fe gG = fe_load_ark<F>(gGw.w), gH = fe_load_ark<F>(gHw.w);
             xl = fe_mul<F>(xl, gG); xr = fe_mul<F>(xr, gG);
-            yl = fe_mul<F>(yl, gH); yr = fe_mul<F>(yr, gH);
+            if (pending == 2) {   // geometric pending factor: yl pairs with H_L[i] (index i), yr with H_R[i] (index n + i)
+                const Fe ri = fe_mul<F>(gH, pow_table<F>(rho_pow, i));
+                yl = fe_mul<F>(yl, ri);
+                yr = fe_mul<F>(yr, fe_mul<F>(ri, pow_table<F>(rho_pow, n)));
+            } else {
+                yl = fe_mul<F>(yl, gH); yr = fe_mul<F>(yr, gH);
+            }
         }
         store_fe_canon<F>(sL + (size_t)i * 8, xl);
         store_fe_canon<F>(sL + (size_t)(n + i) * 8, yl);

@@ -17,14 +17,7 @@
 
 namespace arkbp {
 
-// x^e from a table of x^(2^k) (resident words), e < 2^32
-template <class F> __device__ __forceinline__ Fe pow_from_table(const u32* __restrict__ tab, u32 e) {
-    Fe r = fe_one<F>();
-#pragma unroll 1
-    for (int k = 0; e; k++, e >>= 1)
-        if (e & 1) r = fe_mul<F>(r, load_fe_dev<F>(tab + (size_t)k * 8));
-    return r;
-}
+template <class F> __device__ __forceinline__ Fe pow_from_table(const u32* __restrict__ tab, u32 e) { return pow_table<F>(tab, e); }
 
 // ypow: 64 x 8 words: y^(2^k) for k < 32, then y^-(2^k) for k < 32.
 // partials: gridDim.x x 6 x 8 words.

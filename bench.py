@@ -207,6 +207,7 @@ def run_prove(args, rank, world, local):
                 if i is None:
                     return
                 out[i] = stmts[i].prove(engs[k])
+                stmts[i].free()   # a consumed statement (witness + constraints, ~0.3 GB at 2^20) is released at once
 
         t1 = [threading.Thread(target=stage1) for _ in range(args.host_threads)]
         t2 = [threading.Thread(target=stage2, args=(k,)) for k in range(P)]
