@@ -8,6 +8,7 @@
 // ark-serialize 0.4).  Independent of the test oracle.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -30,6 +31,16 @@ static inline void sha3_512(u8 out[64], const u8* m, size_t n) {
     b[pos] ^= 0x06; b[71] ^= 0x80;
     keccakf(s);
     memcpy(out, b, 64);
+}
+
+// size of the library's own host thread pools: the machine's hardware threads, capped (one process per GPU shares the host
+// with 7 others), overridable with ARKBP_HOST_THREADS
+static inline unsigned host_pool_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    if (n > 32) n = 32;
+    if (const char* e = getenv("ARKBP_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) n = (unsigned)v; }
+    return n;
 }
 
 // ---- ChaCha20Rng (rand_chacha 0.3: 64-bit counter, stream 0, sequential u32 word stream) ------------------
@@ -219,7 +230,7 @@ template <class C> static void derive_generators(std::vector<A4>& out, char whic
     u8 msg[20]; memcpy(msg, "GeneratorsChain", 15); msg[15] = (u8)which; memcpy(msg + 16, &party, 4);
     u8 h[64]; sha3_512(h, msg, 20);
     ChaChaRng prng(h);
-    if (!nthreads) nthreads = std::max(1u, std::thread::hardware_concurrency());
+    if (!nthreads) nthreads = host_pool_threads();
     out.clear(); out.reserve(count);
     struct Attempt { F4 x; bool greatest; };
     while (out.size() < count) {

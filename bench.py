@@ -172,11 +172,12 @@ def run_prove(args, rank, world, local):
         def mk(k):
             out[k] = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], bytes([3 + tag, 1 + (k & 0xFF), k >> 8] + [3] * 29))
 
-        th = [threading.Thread(target=mk, args=(k,)) for k in range(count)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        for lo in range(0, count, 16):   # at most 16 statements under construction at once
+            th = [threading.Thread(target=mk, args=(k,)) for k in range(lo, min(lo + 16, count))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
         return out
 
     def run_pool(stmts, out):

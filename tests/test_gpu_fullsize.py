@@ -1,0 +1,82 @@
+"""Full-size GPU tests through size-independent properties (the CPU oracle cannot reach these sizes in seconds):
+prove -> verify round trips at 2^14 / 2^16 constraints with tamper rejection, MSM linearity at 2^20 terms, batch verify
+of mixed large proofs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import ark_bulletproofs_amd as A
+
+    e = A.Engine(curve=0)
+    e.gens_derive(1 << 16)
+    yield e
+    e.close()
+
+
+def test_prove_verify_roundtrip_2pow16(eng):
+    N = 1 << 16
+    pr = eng.prove_scenario(3, [N, 0], bytes([3]) * 32, m_cap=8)
+    assert len(pr.proof) == 539 + 66 * 16
+    assert eng.verify_scenario(3, [N, 0], pr.proof, pr.commitments, pr.publics) == 0
+    bad = bytearray(pr.proof)
+    bad[-1] ^= 1  # ipp b
+    assert eng.verify_scenario(3, [N, 0], bytes(bad), pr.commitments, pr.publics) in (-4, -6)
+    wrong = pr.publics.copy()
+    wrong[0, 0] ^= np.uint64(2)
+    assert eng.verify_scenario(3, [N, 0], pr.proof, pr.commitments, wrong) == -4
+    # a wrong witness (public output off by one) yields a proof that must not verify
+    pr_bad = eng.prove_scenario(3, [N, 1], bytes([3]) * 32, m_cap=8)
+    assert eng.verify_scenario(3, [N, 1], pr_bad.proof, pr_bad.commitments, pr_bad.publics) == -4
+
+
+def test_cfg4_shape_prove_and_batch_verify(eng):
+    """BASELINE cfg4 statement shape: 256 x 64-bit range proofs in one circuit (n = 2^14, m = 256, 0/1 witness vectors:
+    the skewed-bucket path of the MSM), batch-verified together with a shuffle and a square chain of other sizes."""
+    inst = []
+    for i in range(3):
+        pr = eng.prove_scenario(4, [256, 64, 0], bytes([4, i] + [4] * 30), m_cap=264)
+        assert len(pr.commitments) == 256
+        inst.append((4, [256, 64, 0], pr.proof, pr.commitments, pr.publics))
+    pr = eng.prove_scenario(0, [1000], bytes([9]) * 32, m_cap=2008)       # k-shuffle: 2-phase, 1998 multipliers -> 2048
+    inst.append((0, [1000], pr.proof, pr.commitments, pr.publics))
+    pr = eng.prove_scenario(3, [5000, 0], bytes([8]) * 32, m_cap=8)         # non-power-of-two: padding path
+    inst.append((3, [5000, 0], pr.proof, pr.commitments, pr.publics))
+    for sc, prm, proof, cm, pb in inst:
+        assert eng.verify_scenario(sc, prm, proof, cm, pb) == 0
+    rc, _ = eng.batch_verify(inst, bytes([5]) * 32)
+    assert rc == 0
+    sc, prm, proof, cm, pb = inst[1]
+    bad = bytearray(proof)
+    bad[11 * 33 + 3] ^= 4
+    inst[1] = (sc, prm, bytes(bad), cm, pb)
+    rc, _ = eng.batch_verify(inst, bytes([5]) * 32)
+    assert rc == -4
+
+
+def test_msm_linearity_2pow20(eng):
+    """msm(b || b, s1 || s2) == msm(b, s1) + msm(b, s2) and msm is invariant under a permutation of its terms"""
+    from ark_bulletproofs_amd import engine as E
+
+    n = 1 << 19
+    G, H = eng.gens_download(1 << 16)
+    bases = np.tile(np.concatenate([G, H]), (n // (1 << 17), 1))            # 2^19 bases (repeats are fine)
+    rng = np.random.default_rng(7)
+    s1 = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    s2 = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    s1[:, 3] >>= np.uint64(2)
+    s2[:, 3] >>= np.uint64(2)
+    db = eng.upload_points(np.concatenate([bases, bases]))
+    ds = eng.upload_scalars(np.concatenate([s1, s2]))
+    full = eng.msm_dev(db, ds, 2 * n)
+    db1, ds1, ds2 = eng.upload_points(bases), eng.upload_scalars(s1), eng.upload_scalars(s2)
+    a, b = eng.msm_dev(db1, ds1, n), eng.msm_dev(db1, ds2, n)
+    assert (E.host_points_sum(0, np.stack([a, b])) == full).all()
+    perm = rng.permutation(n)
+    dbp, dsp = eng.upload_points(bases[perm]), eng.upload_scalars(s1[perm])
+    assert (eng.msm_dev(dbp, dsp, n) == a).all()
+    for d in (db, ds, db1, ds1, ds2, dbp, dsp):
+        d.free()
