@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Xarch_host", "-march=x86-64-v3",
-           "-Wno-unused-result", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-result"] + (["-DARKBP_MSM_CH=" + os.environ["ARKBP_MSM_CH"]] if os.environ.get("ARKBP_MSM_CH") else []) + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -23,7 +23,10 @@
 
 namespace arkbp {
 
-static constexpr int MSM_CH = 16;      // entries per level-1 lane / fan-in of the reduction tree
+#ifndef ARKBP_MSM_CH
+#define ARKBP_MSM_CH 16
+#endif
+static constexpr int MSM_CH = ARKBP_MSM_CH;  // entries per level-1 lane / fan-in of the reduction tree
 static constexpr int MSM_MAXLVL = 8;   // 16^8 = 2^32 >= any bucket population
 static constexpr int MSM_MAXSEG = 4;
 
