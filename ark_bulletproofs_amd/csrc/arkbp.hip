@@ -795,6 +795,17 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src) {
     return BP_OK;
 }
 
+int bp_ipa_verify(bp_ctx* c, size_t n, const uint64_t* G_factors, const uint64_t* H_factors, const uint64_t P_xy[8], const uint64_t Q_xy[8],
+                  const uint64_t* G_xy, const uint64_t* H_xy, const uint64_t* L_xy, const uint64_t* R_xy, size_t lg_n, const uint64_t* challenges,
+                  const uint64_t a[4], const uint64_t b[4]) {
+    if (!c || !n || !G_factors || !H_factors || !P_xy || !Q_xy || !G_xy || !H_xy || !a || !b || (lg_n && (!L_xy || !R_xy || !challenges))) {
+        g_err = "bp_ipa_verify: bad argument"; return BP_E_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? ipa_verify_host_entry<Secq>(c, n, G_factors, H_factors, P_xy, Q_xy, G_xy, H_xy, L_xy, R_xy, lg_n, challenges, a, b)
+                         : ipa_verify_host_entry<Zorro>(c, n, G_factors, H_factors, P_xy, Q_xy, G_xy, H_xy, L_xy, R_xy, lg_n, challenges, a, b);
+}
+
 int bp_ctx_set_profiling(bp_ctx* c, int enabled) { if (!c) return BP_E_ARG; c->profiling = enabled != 0; return BP_OK; }
 int bp_ctx_kernel_time(bp_ctx* c, int which, double* ms_total, uint64_t* launches) {
     if (!c || which < 0 || which >= BP_K_COUNT) return BP_E_ARG;

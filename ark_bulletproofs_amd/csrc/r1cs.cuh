@@ -153,6 +153,26 @@ k_vfy_scalars(const u32* __restrict__ wL, const u32* __restrict__ wR, const u32*
         store_fe_canon<F>(h_out + o, h);
     }
 }
+// InnerProductProof::verify scalars (src/inner_product_proof.rs:338-352): g[i] = a * s[i] * G_factors[i],
+// h[i] = b * s[n-1-i] * H_factors[i] as canonical integers.  consts: resident words [allinv, a, b]; chal: u_sq[k].
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_vfy_scalars(const u32* __restrict__ Gf, const u32* __restrict__ Hf, const u32* __restrict__ chal, const u32* __restrict__ consts, u32 n, u32 k,
+                  u32* __restrict__ g_out, u32* __restrict__ h_out) {
+    typedef typename C::Fr F;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fe allinv = load_fe_dev<F>(consts), a = load_fe_dev<F>(consts + 8), b = load_fe_dev<F>(consts + 16);
+    Fe s_i = allinv, s_rev = allinv;
+#pragma unroll 1
+    for (u32 j = 0; j < k; j++) {
+        const Fe usq = load_fe_dev<F>(chal + (size_t)(k - 1 - j) * 8);
+        if ((i >> j) & 1) s_i = fe_mul<F>(s_i, usq); else s_rev = fe_mul<F>(s_rev, usq);
+    }
+    const size_t o = (size_t)i * 8;
+    store_fe_canon<F>(g_out + o, fe_mul<F>(fe_mul<F>(a, s_i), load_fe_dev<F>(Gf + o)));
+    store_fe_canon<F>(h_out + o, fe_mul<F>(fe_mul<F>(b, s_rev), load_fe_dev<F>(Hf + o)));
+}
+
 // resident form -> canonical integers, in place
 template <class F> __global__ void k_scalars_to_canon(u32* __restrict__ v, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;

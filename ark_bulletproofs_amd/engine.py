@@ -365,3 +365,18 @@ def precompute_batch(stmts):
     """host-only head of prove() for many statements; groups of 8 same-shaped ones share one AVX-512 Keccak-f x8 stream"""
     arr = (C.c_void_p * len(stmts))(*[s.h for s in stmts])
     check(lib().bp_stmt_precompute_batch(arr, C.c_size_t(len(stmts))), "bp_stmt_precompute_batch")
+
+
+def _ipa_verify(self, n, G_factors, H_factors, P, Q, G_vec, H_vec, L_vec, R_vec, challenges, a, b):
+    """InnerProductProof::verify; challenges = the u_j the caller's transcript replay produced.  Returns the C status."""
+    Lv = np.ascontiguousarray(L_vec, dtype=np.uint64).reshape(-1, 8)
+    Rv = np.ascontiguousarray(R_vec, dtype=np.uint64).reshape(-1, 8)
+    ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1, 4)
+    k = len(Lv)
+    pad8, pad4 = np.zeros((1, 8), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64)
+    arrs = [u64arr(G_factors, 4), u64arr(H_factors, 4), u64arr(P, 8), u64arr(Q, 8), u64arr(G_vec, 8), u64arr(H_vec, 8)]
+    return lib().bp_ipa_verify(self.ctx, C.c_size_t(n), *[ptr(x) for x in arrs], ptr(Lv if k else pad8), ptr(Rv if k else pad8), C.c_size_t(k),
+                               ptr(ch if k else pad4), ptr(u64arr(a, 4)), ptr(u64arr(b, 4)))
+
+
+Engine.ipa_verify = _ipa_verify

@@ -76,6 +76,15 @@ int bp_ipa_create(bp_ctx* ctx, const uint64_t Q_xy[8], const uint64_t* G_factors
                   const uint64_t* H_xy, const uint64_t* a, const uint64_t* b, size_t n, bp_challenge_cb cb, void* user, uint64_t* L_out_xy,
                   uint64_t* R_out_xy, uint64_t a_out[4], uint64_t b_out[4]);
 
+/* ---- InnerProductProof::verify -------------------------------------------------------------------
+ * Replaces `proof.verify(n, transcript, G_factors, H_factors, &P, &Q, &G, &H)` (src/inner_product_proof.rs:321-382).
+ * The caller replays its transcript (`innerproduct_domain_sep`, `validate_and_append_point(L|R)`, `challenge_scalar(u)`,
+ * :266-277) and passes the lg_n challenges in creation order; the engine derives u^2, u^-2, the s vector (:279-311), builds
+ * the 1 + 2n + 2 lg_n scalars on the GPU, runs the MSM and compares with P.  Returns BP_OK or BP_E_VERIFICATION. */
+int bp_ipa_verify(bp_ctx* ctx, size_t n, const uint64_t* G_factors, const uint64_t* H_factors, const uint64_t P_xy[8], const uint64_t Q_xy[8],
+                  const uint64_t* G_xy, const uint64_t* H_xy, const uint64_t* L_xy, const uint64_t* R_xy, size_t lg_n, const uint64_t* challenges,
+                  const uint64_t a[4], const uint64_t b[4]);
+
 /* ---- generators -----------------------------------------------------------------------------------
  * bp_gens_derive replaces `BulletproofGens::new(cap, 1)` + `PedersenGens::default()` (src/generators.rs:174-221,
  * 47-66): derives party 0's G/H tables on the host cores and installs them in HBM (resident for the life of

@@ -72,3 +72,48 @@ def test_ipa_rejects_bad_lengths(eng, oracle):
         eng.ipa_create(Q, Gf, Hf, G, H, a[:3], b, lambda L, R: a[0])
     with pytest.raises(A.ArkbpError):  # n = 3 is not a power of two
         eng.ipa_create(Q, Gf[:3], Hf[:3], G[:3], H[:3], a[:3], b[:3], lambda L, R: a[0])
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 32, 64])
+def test_ipa_verify_on_gpu(eng, oracle, n):
+    """InnerProductProof::verify (src/inner_product_proof.rs:321-382) on the GPU: same accept/reject as the oracle,
+    on the reference's own make_ipp sizes (:530-553)."""
+    O, cv = oracle, eng.curve
+    FR = O.fid(cv, True)
+    G, H, Q, a, b, Gf, Hf, P = _ipa_instance(O, cv, n)
+    L, R, ao, bo = O.ipa_create(cv, O.Transcript(b"innerproducttest"), Q, Gf, Hf, G, H, a, b)
+    # the caller's transcript replay yields the challenges
+    tr = O.Transcript(b"innerproducttest")
+    tr.append_message(b"dom-sep", b"ipp v1")
+    tr.append_u64(b"n", n)
+    ch = []
+    for j in range(len(L)):
+        tr.append_point(cv, b"L", L[j])
+        tr.append_point(cv, b"R", R[j])
+        ch.append(tr.challenge_scalar(cv, b"u"))
+    ch = np.array(ch).reshape(-1, 4)
+    assert eng.ipa_verify(n, Gf, Hf, P, Q, G, H, L, R, ch, ao, bo) == 0
+    assert O.ipa_verify(cv, O.Transcript(b"innerproducttest"), n, Gf, Hf, P, Q, G, H, L, R, ao, bo) == 0
+    bad_a = O.fe_op("add", FR, ao, O.fe_from_int(FR, 1))
+    assert eng.ipa_verify(n, Gf, Hf, P, Q, G, H, L, R, ch, bad_a, bo) == -4
+    assert eng.ipa_verify(n, Gf, Hf, G[0], Q, G, H, L, R, ch, ao, bo) == -4            # wrong P
+    if n > 1:
+        L2 = L.copy()
+        L2[0] = R[0]
+        assert eng.ipa_verify(n, Gf, Hf, P, Q, G, H, L2, R, ch, ao, bo) == -4
+        assert eng.ipa_verify(n, Gf, Hf, P, Q, G, H, L[:-1], R[:-1], ch[:-1], ao, bo) == -4  # n != 2^lg_n
+    # a proof created on the GPU verifies on the GPU
+    tr_g = O.Transcript(b"innerproducttest")
+    tr_g.append_message(b"dom-sep", b"ipp v1")
+    tr_g.append_u64(b"n", n)
+    chg = []
+
+    def chal(Lp, Rp):
+        tr_g.append_point(cv, b"L", Lp)
+        tr_g.append_point(cv, b"R", Rp)
+        u = tr_g.challenge_scalar(cv, b"u")
+        chg.append(u)
+        return u
+
+    Lg, Rg, ag, bg = eng.ipa_create(Q, Gf, Hf, G, H, a, b, chal)
+    assert eng.ipa_verify(n, Gf, Hf, P, Q, G, H, Lg, Rg, np.array(chg).reshape(-1, 4), ag, bg) == 0
