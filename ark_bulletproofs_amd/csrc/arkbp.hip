@@ -113,10 +113,12 @@ static MsmPlan msm_plan(size_t n, int bits) {
         if (cost < best) { best = cost; bc = c; }
     }
     MsmPlan pl; pl.c = bc; pl.W = bits / bc + 1; pl.NB = 1 << (bc - 1); pl.B = (u32)pl.W * pl.NB; pl.n = (u32)n;
+    pl.w_lo = 0; pl.w_hi = pl.W;
     return pl;
 }
 
-template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u32* d_scalars, size_t n, int scalars_mont, J4& result) {
+template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u32* d_scalars, size_t n, int scalars_mont, J4& result,
+                                      int w_lo = 0, int w_hi = -1 /* window range for multi-GPU window sharding; default all */) {
     typedef host::Grp<C> G;
     typedef host::Fld<typename C::Fq> F;
     result = G::inf();
@@ -124,6 +126,8 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (n >= (1u << 31)) { g_err = "msm: n too large"; return BP_E_ARG; }
     hipStream_t st = ctx->stream;
     MsmPlan pl = msm_plan(n, C::Fr::BITS);
+    if (w_hi >= 0) { pl.w_lo = std::max(0, w_lo); pl.w_hi = std::min(pl.W, w_hi); }
+    if (pl.w_lo >= pl.w_hi) return BP_OK;  // this rank owns no window: the identity
     constexpr int NL = MSM_NLMAX;
     int nl = 2;  // levels 0..nl-1 can be needed: 16^(nl-1) >= n
     { u64 cap = MSM_CH; while (cap < n && nl < NL) { cap *= MSM_CH; nl++; } }
@@ -222,11 +226,12 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
 
 template <class C> static void aff_out(uint64_t out[8], const A4& a) { memcpy(out, a.x.v, 32); memcpy(out + 4, a.y.v, 32); }
 
-template <class C> static int msm_dev_entry(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int canonical, uint64_t out_xy[8]) {
+template <class C> static int msm_dev_entry(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int canonical, uint64_t out_xy[8],
+                                            int w_lo = 0, int w_hi = -1) {
     BaseSegs segs; memset(&segs, 0, sizeof segs);
     segs.nseg = 1; segs.ptr[0] = (const u32*)d_bases; segs.start[0] = 0; segs.start[1] = (u32)n;
     J4 r;
-    BPCHK(msm_run<C>(ctx, segs, (const u32*)d_scalars, n, canonical ? 0 : 1, r));
+    BPCHK(msm_run<C>(ctx, segs, (const u32*)d_scalars, n, canonical ? 0 : 1, r, w_lo, w_hi));
     A4 a = host::Grp<C>::to_aff(r);
     memcpy(out_xy, a.x.v, 32); memcpy(out_xy + 4, a.y.v, 32);
     if (ctx->profiling) collect_timers(ctx);
@@ -580,6 +585,19 @@ int bp_msm_dev(bp_ctx* c, const void* d_bases, const void* d_scalars, size_t n, 
     if (!c || !out_xy || ((!d_bases || !d_scalars) && n)) { g_err = "bp_msm_dev: bad argument"; return BP_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
     return c->curve == 0 ? msm_dev_entry<Secq>(c, d_bases, d_scalars, n, canonical, out_xy) : msm_dev_entry<Zorro>(c, d_bases, d_scalars, n, canonical, out_xy);
+}
+int bp_msm_window_count(int curve, size_t n, int* windows, int* window_bits) {
+    if ((curve != 0 && curve != 1) || !windows) return BP_E_ARG;
+    MsmPlan pl = msm_plan(n ? n : 1, curve == 0 ? Secq::Fr::BITS : Zorro::Fr::BITS);
+    *windows = pl.W;
+    if (window_bits) *window_bits = pl.c;
+    return BP_OK;
+}
+int bp_msm_dev_windows(bp_ctx* c, const void* d_bases, const void* d_scalars, size_t n, int canonical, int w_lo, int w_hi, uint64_t out_xy[8]) {
+    if (!c || !out_xy || ((!d_bases || !d_scalars) && n) || w_lo < 0 || w_hi < w_lo) { g_err = "bp_msm_dev_windows: bad argument"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? msm_dev_entry<Secq>(c, d_bases, d_scalars, n, canonical, out_xy, w_lo, w_hi)
+                         : msm_dev_entry<Zorro>(c, d_bases, d_scalars, n, canonical, out_xy, w_lo, w_hi);
 }
 int bp_msm(bp_ctx* c, const uint64_t* bases_xy, const uint64_t* scalars, size_t n, int canonical, uint64_t out_xy[8]) {
     if (!c || !out_xy || ((!bases_xy || !scalars) && n)) { g_err = "bp_msm: bad argument"; return BP_E_ARG; }

@@ -48,6 +48,7 @@ struct MsmPlan {
     int c, W, NB;        // window bits, windows, buckets per window (2^(c-1))
     u32 B;               // W * NB
     u32 n;
+    int w_lo, w_hi;      // windows this call accumulates (multi-GPU window sharding); [0, W) = all
 };
 
 // One-pass sort: bucket (w, v) owns the fixed slot range [base[w] + v*cap[w], +cap[w]) so the histogram pass can place
@@ -155,8 +156,8 @@ k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __re
     }
     u32 carry = 0;
     for (int w = 0; w < pl.W; w++) {
-        const int d = msm_digit(k, w, pl.c, carry);
-        const bool valid = live && d != 0;
+        const int d = msm_digit(k, w, pl.c, carry);   // every window is decoded: the signed-digit carry chains through all of them
+        const bool valid = live && d != 0 && w >= pl.w_lo && w < pl.w_hi;
         const u32 v = (u32)(d < 0 ? -d : d) - 1;
         const u32 pos = wave_count(hist, (u32)w * pl.NB + v, valid);
         if (valid) {
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ can
     u32 carry = 0;
     for (int w = 0; w < pl.W; w++) {
         const int d = msm_digit(k, w, pl.c, carry);
-        const bool valid = live && d != 0;
+        const bool valid = live && d != 0 && w >= pl.w_lo && w < pl.w_hi;
         const u32 pos = wave_count(cursor, (u32)w * pl.NB + (u32)(d < 0 ? -d : d) - 1, valid);
         if (valid) entries[pos] = (i << 1) | (d < 0 ? 1u : 0u);
     }

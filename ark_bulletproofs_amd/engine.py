@@ -380,3 +380,19 @@ def _ipa_verify(self, n, G_factors, H_factors, P, Q, G_vec, H_vec, L_vec, R_vec,
 
 
 Engine.ipa_verify = _ipa_verify
+
+
+def msm_window_count(curve, n):
+    """(windows, window_bits) of the engine's Pippenger schedule for an n-term MSM; depends only on (curve, n)"""
+    w, c = C.c_int(0), C.c_int(0)
+    check(lib().bp_msm_window_count(curve, C.c_size_t(n), C.byref(w), C.byref(c)), "bp_msm_window_count")
+    return w.value, c.value
+
+
+def _msm_dev_windows(self, d_bases, d_scalars, n, w_lo, w_hi, canonical=False):
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib().bp_msm_dev_windows(self.ctx, d_bases.ptr, d_scalars.ptr, C.c_size_t(n), int(canonical), int(w_lo), int(w_hi), ptr(out)), "bp_msm_dev_windows")
+    return out
+
+
+Engine.msm_dev_windows = _msm_dev_windows

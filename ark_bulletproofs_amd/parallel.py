@@ -4,6 +4,7 @@ ONE 64-byte partial point per rank per MSM (group addition is not an RCCL reduct
 local (world-1)-add point-reduce).  SURVEY.md §8(e).
 
   sharded_msm           term sharding: rank r owns terms [lo_r, hi_r) of bases/scalars
+  window_sharded_msm    window sharding: every rank holds all terms and owns a range of Pippenger windows
   sharded_batch_verify  whole proofs per rank; by linearity the sum of the per-rank mega-check points is the
                         reference's single MSM (src/r1cs/verifier.rs:685)
 """
@@ -36,6 +37,15 @@ def sharded_msm(curve, local_msm, points_sum, group=None, device=None):
     """local_msm() -> this rank's partial MSM (affine, 8 x u64); returns the full MSM value on every rank"""
     parts = allgather_points(local_msm(), group, device)
     return points_sum(curve, parts)
+
+
+def window_sharded_msm(curve, n, local_msm_windows, window_count, points_sum, rank, world, group=None, device=None):
+    """Window sharding (every rank holds all bases and scalars): rank r accumulates Pippenger windows [lo_r, hi_r) of the
+    window_count(curve, n)[0] windows; local_msm_windows(lo, hi) -> that partial, already weighted by 2^(c*w)."""
+    W, _ = window_count(curve, n)
+    lo, hi = shard_range(W, rank, world)
+    part = local_msm_windows(lo, hi) if hi > lo else np.zeros(8, dtype=np.uint64)
+    return points_sum(curve, allgather_points(part, group, device))
 
 
 def sharded_batch_verify(curve, instances, local_batch_verify, points_sum, rank, world, group=None, device=None):

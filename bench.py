@@ -100,7 +100,7 @@ def run_msm(args, rank, world, local):
 
     n = args.terms
     eng = A.Engine(curve=args.curve, device=local)
-    bases, sc = synth_msm_inputs(eng, n, rank)
+    bases, sc = synth_msm_inputs(eng, n, 0 if args.shard == "windows" else rank)
     db, ds = eng.upload_points(bases), eng.upload_scalars(sc)
     for _ in range(args.warmup):
         eng.msm_dev(db, ds, n)
@@ -109,8 +109,13 @@ def run_msm(args, rank, world, local):
     barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        # term-sharded MSM: local partial, all-gather of one 64-byte point per rank over RCCL, host point-reduce
-        full = P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device="cuda" if world > 1 else None)
+        if args.shard == "windows":
+            # window-sharded MSM (north_star): every rank holds the same n terms and owns a range of Pippenger windows
+            full = P.window_sharded_msm(args.curve, n, lambda lo, hi: eng.msm_dev_windows(db, ds, n, lo, hi), E.msm_window_count, E.host_points_sum,
+                                        rank, world, device="cuda" if world > 1 else None)
+        else:
+            # term-sharded MSM: local partial, all-gather of one 64-byte point per rank over RCCL, host point-reduce
+            full = P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device="cuda" if world > 1 else None)
     barrier(world)
     dt = time.perf_counter() - t0
     if world > 1:
@@ -122,11 +127,12 @@ def run_msm(args, rank, world, local):
     acc_ms, acc_n = eng.kernel_time(0)
     tot_ms, tot_n = eng.kernel_time(1)
     res = {
-        "metric": "msm_terms_per_sec", "value": n * world * args.steps / dt, "unit": "terms/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "msm_terms_per_sec", "value": n * (1 if args.shard == "windows" else world) * args.steps / dt, "unit": "terms/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if args.shard == "windows" else "weak", "vs_baseline": None,
         "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
         "config": {"workload": "cfg2: 2^%d-term variable-base MSM, %s, inputs HBM-resident" % (int(np.log2(n)), ["secq256k1", "zorro"][args.curve]),
-                   "terms_per_gpu": n, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": "term-sharded x%d" % world},
+                   "terms_per_gpu": n, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": "%s-sharded x%d" % (args.shard[:-1], world)},
     }
     if acc_n:
         avg_s = acc_ms / acc_n * 1e-3
@@ -393,6 +399,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=3, help="host threads running the TranscriptRng head of prove()")
     ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--terms", type=int, default=1 << 16)
+    ap.add_argument("--shard", default="terms", choices=["terms", "windows"], help="multi-GPU MSM sharding (msm workload)")
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -64,6 +64,14 @@ int bp_msm(bp_ctx* ctx, const uint64_t* bases_xy, const uint64_t* scalars, size_
  * 32 B.  This is the call the timed region of bench.py makes. */
 int bp_msm_dev(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int scalars_canonical, uint64_t out_xy[8]);
 
+/* Window-sharded MSM for one large MSM across the GPUs of a node (every GPU holds all bases and scalars): the call
+ * accumulates only Pippenger windows [w_lo, w_hi) of the bp_msm_window_count(curve, n) windows and returns that partial
+ * sum already weighted by 2^(c*w); the ranks' partials add up to the full MSM (all-gather of one 64-byte point per rank,
+ * then bp_host_points_sum).  The window schedule depends only on (curve, n), so all ranks agree on it. */
+int bp_msm_window_count(int curve, size_t n, int* windows, int* window_bits);
+int bp_msm_dev_windows(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int scalars_canonical, int w_lo, int w_hi,
+                       uint64_t out_xy[8]);
+
 /* ---- InnerProductProof::create -------------------------------------------------------------------
  * Replaces `InnerProductProof::create(transcript, &Q, &G_factors, &H_factors, G_vec, H_vec, a_vec, b_vec)`
  * (src/inner_product_proof.rs:37-239).  Host buffers of length n (a power of two, as the reference

@@ -133,3 +133,30 @@ def test_msm_cfg2_2pow16(eng, oracle):
     assert (eng.msm_dev(db, ds, n) == got).all()
     db.free()
     ds.free()
+
+
+def test_msm_window_sharding(eng, oracle):
+    """north_star's multi-GPU MSM: GPU g accumulates a range of Pippenger windows; the partials (already weighted by
+    2^(c*w)) must add up to the full MSM.  Emulated on one GPU with 1, 3 and 8 'ranks'."""
+    from ark_bulletproofs_amd import engine as E
+    from ark_bulletproofs_amd.parallel import shard_range
+
+    O, cv = oracle, eng.curve
+    n = 5000
+    G, H = O.bp_gens(cv, n // 2)
+    bases = np.concatenate([G, H])
+    sc = _rand_scalars(O, cv, n, 6)
+    exp = O.msm(cv, bases, sc)
+    db, ds = eng.upload_points(bases), eng.upload_scalars(sc)
+    W, c = E.msm_window_count(cv, n)
+    assert W * c >= 255 and W > 8
+    for world in (1, 3, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = shard_range(W, r, world)
+            parts.append(eng.msm_dev_windows(db, ds, n, lo, hi))
+        assert (E.host_points_sum(cv, np.stack(parts)) == exp).all()
+    assert not eng.msm_dev_windows(db, ds, n, 3, 3).any()          # empty range -> identity
+    assert (eng.msm_dev_windows(db, ds, n, 0, W) == exp).all()
+    db.free()
+    ds.free()
