@@ -4,7 +4,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <functional>
+#include <map>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/arkbp.h"
@@ -71,6 +74,9 @@ struct bp_ctx {
     A4 pc_B, pc_Bb;
     // R1CS prover / verifier vectors (resident scalar layout)
     DevBuf r_aL, r_aR, r_aO, r_sL, r_sR, r_wL, r_wR, r_wO, r_msmsc, r_ypow, r_part, r_small, r_g, r_h, r_chal, r_tail;
+    // batch verification: per-proof parameter blocks, chunk partials; cached circuit templates (VTemplate<C>)
+    DevBuf v_params, v_gpart, v_hpart;
+    std::map<std::string, std::shared_ptr<void>> templates;
     u32* h_totals = nullptr;  // pinned
     u32* h_T = nullptr;       // pinned
     size_t h_T_cap = 0;
@@ -525,7 +531,8 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q,
                       &c->d_G, &c->d_H, &c->d_pc, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
-                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail};
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart};
+    c->templates.clear();
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);

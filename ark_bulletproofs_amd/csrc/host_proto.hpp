@@ -530,6 +530,26 @@ template <class C> static int scenario_verifier(ConstraintSystem<C>& cs, int sc,
     return BP_E_ARG;
 }
 
+// The transcript side of statement construction alone (Verifier::commit appends, plus the scenario's own domain separator):
+// what remains per instance when the constraint matrices come from a cached template.  Only for single-phase scenarios.
+template <class C> static int scenario_verifier_transcript(Transcript& tr, int sc, const u64* prm, const StatementIO& io) {
+    size_t expect = 0;
+    switch (sc) {
+        case SC_SHUFFLE:   // only k = 1 is single-phase (benches/r1cs_secq256k1.rs:43-46); same prefix as scenario_verifier
+            expect = 2 * prm[0];
+            tr.append_message("dom-sep", "ShuffleProof"); tr.append_u64("k", prm[0]);
+            break;
+        case SC_RANGE: expect = 1; break;
+        case SC_EXAMPLE: expect = 5; break;
+        case SC_SQUARE_CHAIN: expect = 1; if (io.publics.size() != 1) return BP_E_ARG; break;
+        case SC_MULTI_RANGE: expect = prm[0]; break;
+        default: return BP_E_ARG;
+    }
+    if (io.commitments.size() != expect) return BP_E_ARG;
+    for (auto& Vp : io.commitments) TP<C>::append_point(tr, "V", Vp);
+    return BP_OK;
+}
+
 // ---- R1CSProof (src/r1cs/proof.rs:27-91) ---------------------------------------------------------------------
 struct ProofData {
     A4 A_I1, A_O1, S1, A_I2, A_O2, S2, T_1, T_3, T_4, T_5, T_6;

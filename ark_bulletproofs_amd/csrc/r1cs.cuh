@@ -153,6 +153,109 @@ k_vfy_scalars(const u32* __restrict__ wL, const u32* __restrict__ wR, const u32*
         store_fe_canon<F>(h_out + o, h);
     }
 }
+// ---- batch verification of proofs that share one circuit template (same constraint matrices) -------------------------
+// The reference's batch_verify runs verification_scalars per proof on the CPU (src/r1cs/verifier.rs:617-627): flattened
+// constraints (O(nnz)), the s vector, g/h scalars (O(N)) — then alpha-scales and scatter-adds (:649-664).  Here the
+// constraint matrices W_L, W_R, W_O live on the GPU once, in CSC form (column = multiplier index; entry = (constraint q,
+// coefficient id)), and ONE launch handles a whole set of proofs: lane (i, chunk) walks the proofs of its chunk and keeps
+//   sum_p alpha_p * g_p[i],  sum_p alpha_p * h_p[i],  sum_p (alpha_p r_p x_p^2) * y_p^-i wR_p[i] wL_p[i]   (the delta terms)
+// in registers.  Per-proof inputs are a 3.3 KB parameter block (power tables of z and y^-1, challenges, a, b, alpha).
+struct VfyTemplateDev {
+    const u32* col_off[3];   // n+1 each: W_L, W_R, W_O columns
+    const u32* ent_q;        // constraint index per entry
+    const u32* ent_c;        // coefficient id per entry
+    const u32* coefs;        // resident words
+    const u32* const_q;      // constant terms (Variable::One) of the constraints: wc = -sum z^(q+1) * coef  (verifier.rs:339-341)
+    const u32* const_c;
+    u32 n_const;
+};
+static constexpr u32 VFY_PB_WORDS = 832;  // ztab[32] | yinv_tab[32] | consts[8]: allinv,x,a,b,u,alpha,coefD,- | u_sq[31] | pad
+static constexpr u32 VFY_PB_SCALARS = VFY_PB_WORDS / 8;
+
+template <class F> __device__ __forceinline__ Fe csc_column(const VfyTemplateDev& t, int vec, u32 i, const u32* __restrict__ ztab) {
+    Fe acc = fe_zero<F>();
+    const u32 b = t.col_off[vec][i], e = t.col_off[vec][i + 1];
+    for (u32 k = b; k < e; k++) {
+        const Fe zq = pow_table<F>(ztab, t.ent_q[k] + 1);   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
+        acc = fe_addr<F>(acc, fe_mul<F>(zq, load_fe_dev<F>(t.coefs + (size_t)t.ent_c[k] * 8)));
+    }
+    return acc;
+}
+
+// grid (ceil(N/256), nchunks).  g_part/h_part: [nchunks][N] resident words; d_part: [nchunks * gridDim.x] resident words.
+template <class C> __global__ void __launch_bounds__(256)
+k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chunk, u32 n, u32 N, u32 k, u32* __restrict__ g_part,
+            u32* __restrict__ h_part, u32* __restrict__ d_part) {
+    typedef typename C::Fr F;
+    __shared__ u32 sh[9 * 256];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 chunk = blockIdx.y;
+    const u32 p0 = chunk * per_chunk, p1 = min(P, p0 + per_chunk);
+    Fe ag = fe_zero<F>(), ah = fe_zero<F>(), ad = fe_zero<F>();
+    if (i < N) {
+        for (u32 p = p0; p < p1; p++) {
+            const u32* pb = params + (size_t)p * VFY_PB_WORDS;
+            const u32* ztab = pb;
+            const u32* ytab = pb + 256;
+            const u32* cst = pb + 512;
+            const u32* usq = pb + 576;
+            const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
+            const Fe alpha = load_fe_dev<F>(cst + 40);
+            Fe s_i = allinv, s_rev = allinv;
+#pragma unroll 1
+            for (u32 j = 0; j < k; j++) {
+                const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - j) * 8);
+                if ((i >> j) & 1) s_i = fe_mul<F>(s_i, q); else s_rev = fe_mul<F>(s_rev, q);
+            }
+            const Fe yni = pow_table<F>(ytab, i);
+            Fe g, h;
+            if (i < n) {
+                const Fe wL = csc_column<F>(t, 0, i, ztab), wR = csc_column<F>(t, 1, i, ztab), wO = csc_column<F>(t, 2, i, ztab);
+                const Fe ywR = fe_mul<F>(yni, wR);
+                g = fe_sub<F, 2>(fe_mul<F>(x, ywR), fe_mul<F>(a, s_i));
+                Fe tt = fe_addr<F>(fe_mul<F>(x, wL), wO);
+                tt = fe_sub<F, 2>(tt, fe_mul<F>(b, s_rev));
+                h = fe_sub<F, 2>(fe_mul<F>(yni, tt), fe_one<F>());
+                ad = fe_addr<F>(ad, fe_mul<F>(load_fe_dev<F>(cst + 48), fe_mul<F>(ywR, wL)));
+            } else {
+                g = fe_neg<F, 2>(fe_mul<F>(a, s_i));
+                h = fe_sub<F, 2>(fe_mul<F>(yni, fe_neg<F, 2>(fe_mul<F>(b, s_rev))), fe_one<F>());
+            }
+            // single-phase statements: n1 = n, so u_or_1 = 1 for i < n and u on the padding (verifier.rs:486-489)
+            if (i >= n) {
+                const Fe u = load_fe_dev<F>(cst + 32);
+                g = fe_mul<F>(g, u);
+                h = fe_mul<F>(h, u);
+            }
+            ag = fe_addr<F>(ag, fe_mul<F>(alpha, g));
+            ah = fe_addr<F>(ah, fe_mul<F>(alpha, h));
+            // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms
+            Fe wcp = fe_zero<F>();
+            for (u32 e = i; e < t.n_const; e += N)
+                wcp = fe_addr<F>(wcp, fe_mul<F>(pow_table<F>(ztab, t.const_q[e] + 1), load_fe_dev<F>(t.coefs + (size_t)t.const_c[e] * 8)));
+            if (t.n_const > i) ad = fe_addr<F>(ad, fe_neg<F, 4>(fe_mul<F>(load_fe_dev<F>(cst + 48), wcp)));
+        }
+        store_fe_dev<F>(g_part + ((size_t)chunk * N + i) * 8, ag);
+        store_fe_dev<F>(h_part + ((size_t)chunk * N + i) * 8, ah);
+    }
+    const Fe dsum = block_sum_fe<F>(ad, sh);
+    if (threadIdx.x == 0) store_fe_dev<F>(d_part + ((size_t)chunk * gridDim.x + blockIdx.x) * 8, dsum);
+}
+// acc_g[i] += sum_c g_part[c][i] (same for h); acc_* in resident form, i < N
+template <class C> __global__ void __launch_bounds__(256)
+k_vfy_batch_fold(const u32* __restrict__ g_part, const u32* __restrict__ h_part, u32 nchunks, u32 N, u32* __restrict__ acc_g, u32* __restrict__ acc_h) {
+    typedef typename C::Fr F;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Fe g = load_fe_dev<F>(acc_g + (size_t)i * 8), h = load_fe_dev<F>(acc_h + (size_t)i * 8);
+    for (u32 c = 0; c < nchunks; c++) {
+        g = fe_addr<F>(g, load_fe_dev<F>(g_part + ((size_t)c * N + i) * 8));
+        h = fe_addr<F>(h, load_fe_dev<F>(h_part + ((size_t)c * N + i) * 8));
+    }
+    store_fe_dev<F>(acc_g + (size_t)i * 8, g);
+    store_fe_dev<F>(acc_h + (size_t)i * 8, h);
+}
+
 // InnerProductProof::verify scalars (src/inner_product_proof.rs:338-352): g[i] = a * s[i] * G_factors[i],
 // h[i] = b * s[n-1-i] * H_factors[i] as canonical integers.  consts: resident words [allinv, a, b]; chal: u_sq[k].
 template <class C> __global__ void __launch_bounds__(256)
