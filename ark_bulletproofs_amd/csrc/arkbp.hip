@@ -831,6 +831,27 @@ int bp_ipa_verify(bp_ctx* c, size_t n, const uint64_t* G_factors, const uint64_t
                          : ipa_verify_host_entry<Zorro>(c, n, G_factors, H_factors, P_xy, Q_xy, G_xy, H_xy, L_xy, R_xy, lg_n, challenges, a, b);
 }
 
+int bp_debug_decompress(bp_ctx* c, const uint8_t* compressed33, size_t n, uint64_t* out_xy, uint32_t* out_ok) {
+    if (!c || (n && (!compressed33 || !out_xy || !out_ok))) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<F4> xs(n); std::vector<u32> fl(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* d = compressed33 + 33 * i;
+        fl[i] = d[32];
+        bool ok = !(fl[i] & 0x3f) && (fl[i] & 0xc0) != 0xc0 &&
+                  (c->curve == 0 ? host::Fld<Secq::Fq>::from_bytes(xs[i], d) : host::Fld<Zorro::Fq>::from_bytes(xs[i], d));
+        if (ok && (fl[i] & 0x40) && !xs[i].is_zero()) ok = false;
+        if (!ok) { xs[i] = F4{{0, 0, 0, 0}}; fl[i] = 0xFFu; }   // malformed framing: reported as not ok below
+    }
+    std::vector<A4> pts; std::vector<u32> okv;
+    BPCHK(c->curve == 0 ? decompress_points<Secq>(c, xs.data(), fl.data(), n, pts, okv) : decompress_points<Zorro>(c, xs.data(), fl.data(), n, pts, okv));
+    for (size_t i = 0; i < n; i++) {
+        out_ok[i] = fl[i] == 0xFFu ? 0 : okv[i];
+        if (out_ok[i]) { memcpy(out_xy + 8 * i, pts[i].x.v, 32); memcpy(out_xy + 8 * i + 4, pts[i].y.v, 32); } else memset(out_xy + 8 * i, 0, 64);
+    }
+    return BP_OK;
+}
+
 int bp_ctx_set_profiling(bp_ctx* c, int enabled) { if (!c) return BP_E_ARG; c->profiling = enabled != 0; return BP_OK; }
 int bp_ctx_kernel_time(bp_ctx* c, int which, double* ms_total, uint64_t* launches) {
     if (!c || which < 0 || which >= BP_K_COUNT) return BP_E_ARG;

@@ -170,6 +170,76 @@ template <class C> ARKBP_HD Aff jac_to_aff(const Jac& p) {
     return jac_to_aff_with_zinv<C>(p, fe_inv<typename C::Fq>(p.Z));
 }
 
+// Tonelli-Shanks square root in Fq (p - 1 = 2^S * t; ark-ff's SqrtPrecomputation::TonelliShanks shape): false for a
+// non-residue.  Either root may come out; callers order (y, -y) canonically like ark-ec's get_ys_from_x_unchecked.
+template <class F> __device__ __noinline__ bool fe_sqrt(Fe& out, const Fe& a_in) {
+    const Fe a = fe_wred<F>(a_in);
+    if (fe_is_zero_mod<F>(a)) { out = fe_zero<F>(); return true; }
+    // w = a^((t-1)/2)
+    Fe w = fe_one<F>();
+#pragma unroll 1
+    for (int wd = 7; wd >= 0; wd--) {
+        const u32 e = F::TS_TM1H[wd];
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; bit--) {
+            w = fe_sqr<F>(w);
+            if ((e >> bit) & 1) w = fe_mul<F>(w, a);
+        }
+    }
+    Fe x = fe_mul<F>(w, a);        // a^((t+1)/2)
+    Fe b = fe_mul<F>(x, w);        // a^t
+    Fe z = fe_const<F, F::TS_Z29>();
+    const Fe one = fe_one<F>();
+    int v = F::TS_S;
+#pragma unroll 1
+    while (!fe_eq_mod<F>(b, one)) {
+        int k = 0;
+        Fe t = b;
+#pragma unroll 1
+        while (!fe_eq_mod<F>(t, one)) {
+            t = fe_sqr<F>(t);
+            if (++k == v) return false;   // a is a non-residue
+        }
+        Fe wz = z;
+        for (int j = 0; j < v - k - 1; j++) wz = fe_sqr<F>(wz);
+        z = fe_sqr<F>(wz);
+        b = fe_mul<F>(b, z);
+        x = fe_mul<F>(x, wz);
+        v = k;
+    }
+    if (!fe_eq_mod<F>(fe_sqr<F>(x), a)) return false;
+    out = x;
+    return true;
+}
+
+// canonical-integer comparison a > b for canonical a, b (ark `Ord for Fp`)
+ARKBP_HD bool fe_canon_gt(const Fe& a, const Fe& b) {
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int i = 8; i >= 0; i--) {
+        if (!decided && a.l[i] != b.l[i]) { gt = a.l[i] > b.l[i]; decided = true; }
+    }
+    return gt;
+}
+
+// SW point from x and the sign flag of ark-serialize's compressed encoding (greatest = flag 0x80: y > -y)
+template <class C> __device__ __forceinline__ bool aff_from_x(Aff& out, const Fe& x_canon_rform, bool greatest) {
+    typedef typename C::Fq F;
+    Fe rhs = fe_mul<F>(fe_sqr<F>(x_canon_rform), x_canon_rform);
+    if (!C::A_ZERO) rhs = fe_norm(fe_add(rhs, fe_times<(C::A_ZERO ? 1 : C::A_SMALL)>(x_canon_rform)));
+    rhs = fe_norm(fe_add(rhs, fe_load_ark<F>(C::B)));
+    Fe y;
+    if (!fe_sqrt<F>(y, rhs)) return false;
+    // order by the canonical INTEGER value (the residue itself, not its Montgomery representative)
+    const Fe yc = fe_canon<F>(fe_mul<F>(y, fe_const<F, F::CANON29>()));
+    const Fe ny = fe_canon<F>(fe_neg<F, 4>(fe_wred<F>(y)));
+    const Fe nyc = fe_canon<F>(fe_mul<F>(ny, fe_const<F, F::CANON29>()));
+    const bool y_is_larger = fe_canon_gt(yc, nyc);
+    out.x = x_canon_rform;
+    out.y = (greatest == y_is_larger) ? fe_canon<F>(y) : ny;
+    return true;
+}
+
 // ---- 64-byte affine points in memory ------------------------------------------------------------
 // ark layout at the C ABI: x || y as 8+8 u32 words, Montgomery w.r.t. 2^256; identity = all zero.
 template <class C> ARKBP_HD Aff aff_load_ark(const u32* w) {

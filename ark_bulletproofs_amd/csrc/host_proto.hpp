@@ -585,6 +585,55 @@ template <class C> static int proof_from_bytes(ProofData& p, const u8* d, size_t
     return ok ? BP_OK : BP_E_FORMAT;
 }
 
+// Two-step decoding for batches: parse_lazy validates the framing and extracts (x, flag) of every compressed point without
+// taking square roots; the y coordinates come back from the GPU (k_points_decompress) and finish_lazy assembles ProofData.
+struct LazyProof {
+    std::vector<F4> xs;        // Montgomery words of x, point order: A_I1,A_O1,S1,A_I2,A_O2,S2,T_1,T_3,T_4,T_5,T_6, L[k], R[k]
+    std::vector<u32> flags;    // ark-serialize flag byte per point
+    F4 t_x, t_x_blinding, e_blinding, a, b;
+    size_t k = 0;
+};
+template <class C> static int proof_parse_lazy(LazyProof& lp, const u8* d, size_t n) {
+    typedef Fld<typename C::Fq> Fq; typedef Fld<typename C::Fr> S;
+    size_t pos = 0;
+    auto pt = [&]() {
+        if (pos + 33 > n) return false;
+        const u8 fl = d[pos + 32];
+        F4 x;
+        bool ok = !(fl & 0x3f) && (fl & 0xc0) != 0xc0 && Fq::from_bytes(x, d + pos);
+        if (ok && (fl & 0x40) && !x.is_zero()) ok = false;
+        pos += 33;
+        if (ok) { lp.xs.push_back(x); lp.flags.push_back(fl); }
+        return ok;
+    };
+    auto sc = [&](F4& s) { if (pos + 32 > n) return false; bool ok = S::from_bytes(s, d + pos); pos += 32; return ok; };
+    auto vec = [&](size_t& len_out) {
+        if (pos + 8 > n) return false;
+        u64 len; memcpy(&len, d + pos, 8); pos += 8;
+        if (len > (n - pos) / 33) return false;
+        for (u64 i = 0; i < len; i++) if (!pt()) return false;
+        len_out = (size_t)len;
+        return true;
+    };
+    for (int i = 0; i < 11; i++) if (!pt()) return BP_E_FORMAT;
+    size_t kl = 0, kr = 0;
+    bool ok = sc(lp.t_x) && sc(lp.t_x_blinding) && sc(lp.e_blinding) && vec(kl) && vec(kr) && sc(lp.a) && sc(lp.b);
+    if (!ok) return BP_E_FORMAT;
+    lp.k = kl;
+    // L_vec and R_vec lengths may differ in a malformed proof; the verifier then fails (zip in verification_scalars)
+    if (kl != kr) { lp.k = (size_t)-1; }
+    return BP_OK;
+}
+static inline void proof_finish_lazy(ProofData& p, const LazyProof& lp, const A4* pts) {
+    p.A_I1 = pts[0]; p.A_O1 = pts[1]; p.S1 = pts[2]; p.A_I2 = pts[3]; p.A_O2 = pts[4]; p.S2 = pts[5];
+    p.T_1 = pts[6]; p.T_3 = pts[7]; p.T_4 = pts[8]; p.T_5 = pts[9]; p.T_6 = pts[10];
+    p.t_x = lp.t_x; p.t_x_blinding = lp.t_x_blinding; p.e_blinding = lp.e_blinding; p.a = lp.a; p.b = lp.b;
+    const size_t total = lp.xs.size() - 11;
+    const size_t kl = lp.k == (size_t)-1 ? total : lp.k;   // unequal lengths: keep everything in L so the length check fails
+    p.L_vec.assign(pts + 11, pts + 11 + std::min(kl, total));
+    p.R_vec.assign(pts + 11 + std::min(kl, total), pts + 11 + total);
+}
+
 static inline size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace host

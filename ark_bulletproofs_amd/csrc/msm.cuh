@@ -353,6 +353,32 @@ k_msm_marginals(const u32* __restrict__ sums, const u32* __restrict__ off, u32* 
     }
 }
 
+// ---- wire codec: ark-serialize compressed SW points (x as 8 Montgomery words + flag byte) -> affine, ark layout ----------
+// Replaces the per-point square root of `R1CSProof::from_bytes` (src/r1cs/proof.rs:83-91; ark-ec get_point_from_x) for a
+// whole batch.  flags: bit 7 = y is the larger root, bit 6 = identity (then x must be 0: checked by the host parser).
+// ok[i] = 0 when x is not on the curve (FormatError upstream).
+template <class C> __global__ void __launch_bounds__(256)
+k_points_decompress(const u32* __restrict__ x_ark, const u32* __restrict__ flags, u32* __restrict__ out_xy_ark, u32* __restrict__ ok, u32 n) {
+    typedef typename C::Fq F;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[16];
+    const u32 fl = flags[i];
+    if (fl & 0x40) {
+        for (int j = 0; j < 16; j++) w[j] = 0;
+        ok[i] = 1;
+    } else {
+        load_words8(w, x_ark + (size_t)i * 8);
+        const Fe x = fe_canon<F>(fe_load_ark<F>(w));
+        Aff p;
+        const bool good = aff_from_x<C>(p, x, (fl & 0x80) != 0);
+        ok[i] = good ? 1u : 0u;
+        if (good) aff_store_ark<C>(w, p); else for (int j = 0; j < 16; j++) w[j] = 0;
+    }
+    store_words8(out_xy_ark + (size_t)i * 16, w);
+    store_words8(out_xy_ark + (size_t)i * 16 + 8, w + 8);
+}
+
 // ---- format conversion kernels -------------------------------------------------------------------
 // ark layout (x||y Montgomery R=2^256, identity = zeros) -> device layout (packed R' form)
 template <class C> __global__ void k_points_ark_to_dev(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {

@@ -293,7 +293,7 @@ def _batch_verify(self, instances, alpha_seed, alpha_skip=0, want_point=False):
     pubs_l = [np.asarray(i[4], dtype=np.uint64).reshape(-1, 4) for i in instances]
     pubs = np.ascontiguousarray(np.concatenate(pubs_l + [np.zeros((1, 4), dtype=np.uint64)]))
     npubs = (C.c_size_t * n)(*[len(p) for p in pubs_l])
-    timing = (C.c_double * 4)()
+    timing = (C.c_double * 5)()
     pt = np.zeros(8, dtype=np.uint64)
     rc = lib().bp_r1cs_batch_verify_scenarios(self.ctx, C.c_size_t(n), scen, ptr(prm), proofs, plens, ptr(cms), ms, ptr(pubs), npubs, bytes(alpha_seed), timing,
                                               C.c_size_t(alpha_skip), ptr(pt))
@@ -396,3 +396,15 @@ def _msm_dev_windows(self, d_bases, d_scalars, n, w_lo, w_hi, canonical=False):
 
 
 Engine.msm_dev_windows = _msm_dev_windows
+
+
+def _debug_decompress(self, compressed):
+    """compressed: bytes of n x 33; returns (points (n,8) u64, ok (n,) u32)"""
+    n = len(compressed) // 33
+    out = np.zeros((n, 8), dtype=np.uint64)
+    ok = np.zeros(n, dtype=np.uint32)
+    check(lib().bp_debug_decompress(self.ctx, bytes(compressed), C.c_size_t(n), ptr(out), ptr(ok)), "bp_debug_decompress")
+    return out, ok
+
+
+Engine.debug_decompress = _debug_decompress

@@ -314,7 +314,7 @@ def run_verify(args, rank, world, local):
     eng.reset_profiling()
     barrier(world)
     t0 = time.perf_counter()
-    tms = np.zeros(4)
+    tms = np.zeros(5)
     ok = True
     for _ in range(args.steps):
         rc, tm, pt = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
@@ -341,7 +341,8 @@ def run_verify(args, rank, world, local):
                                % (args.proofs, ["secq256k1", "zorro"][args.curve]),
                    "proofs_per_gpu": args.proofs, "distinct_proofs": len(distinct), "constraints_per_proof": N, "parallelism": "proof-sharded x%d" % world,
                    "stage_ms_per_step": {"total": tms[0] / args.steps * 1e3, "host_replay": tms[1] / args.steps * 1e3,
-                                         "gpu_scalar_accumulation": tms[2] / args.steps * 1e3, "final_msm": tms[3] / args.steps * 1e3}},
+                                         "gpu_scalar_accumulation": tms[2] / args.steps * 1e3, "final_msm": tms[3] / args.steps * 1e3,
+                                         "decode_and_statement_replay": tms[4] / args.steps * 1e3}},
     }
     if vs_n:
         avg_s = vs_ms / vs_n * 1e-3

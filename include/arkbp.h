@@ -158,8 +158,8 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src);
  * BP_E_VERIFICATION / BP_E_FORMAT / BP_E_GENS_LENGTH exactly where the reference returns the matching R1CSError.
  * bp_r1cs_batch_verify_scenarios replaces `batch_verify(prng, instances, pc_gens, bp_gens)` (:604-691):
  * `count` instances with concatenated proofs / commitments / publics, params 8 u64 per instance; the per-proof
- * alpha is `Fr::rand` of a ChaCha20 rng seeded with alpha_seed.  timing[4] (s): total, host replay, GPU scalar
- * accumulation, final MSM.  Proof-sharded multi-GPU use: rank r passes its slice of the instances, alpha_skip = number
+ * alpha is `Fr::rand` of a ChaCha20 rng seeded with alpha_seed.  timing[5] (s): [0] verification total, [1] host transcript
+ * replay, [2] GPU scalar accumulation, [3] final MSM, [4] proof decoding (point decompression) + statement replay.  Proof-sharded multi-GPU use: rank r passes its slice of the instances, alpha_skip = number
  * of instances on lower ranks (their alphas are drawn and discarded), and receives the affine value of ITS mega-check
  * in check_point_xy (may be NULL); the batch is valid iff the sum of all ranks' points is the identity
  * (bp_host_points_sum after an all-gather) — by linearity that sum is the reference's single MSM (:685). */
@@ -186,6 +186,9 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
 /* ---- unit-test hooks: one field / group operation per element on the GPU -------------------------- */
 /* field: 2*curve + (0 base field | 1 scalar field); op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inv */
 int bp_debug_field_op(bp_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* ark-serialize compressed SW points (33 bytes each: x LE || flag byte) -> affine, on the GPU (the square roots of
+ * `R1CSProof::from_bytes`, src/r1cs/proof.rs:83-91); out_ok[i] = 0 for malformed or off-curve encodings */
+int bp_debug_decompress(bp_ctx* ctx, const uint8_t* compressed33, size_t n, uint64_t* out_xy, uint32_t* out_ok);
 /* op: 0 P+Q (general add), 1 P+Q (mixed add), 2 2P, 3 k*P (k canonical, one per element) */
 int bp_debug_point_op(bp_ctx* ctx, int op, const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* k, uint64_t* out_xy, size_t n);
 

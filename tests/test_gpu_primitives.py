@@ -160,3 +160,33 @@ def test_msm_window_sharding(eng, oracle):
     assert (eng.msm_dev_windows(db, ds, n, 0, W) == exp).all()
     db.free()
     ds.free()
+
+
+def test_point_decompression_on_gpu(eng, oracle):
+    """the wire-codec square roots (R1CSProof::from_bytes) as a kernel: every encoding ark accepts decodes to the same point,
+    everything it rejects is rejected"""
+    O, cv = oracle, eng.curve
+    G, H = O.bp_gens(cv, 200)
+    pts = np.concatenate([G, H])
+    enc = b"".join(O.point_ser(cv, p, True) for p in pts) + bytes(32) + b"\x40"
+    out, ok = eng.debug_decompress(enc)
+    assert ok.all() and (out[:-1] == pts).all() and not out[-1].any()
+    # flipped sign flag -> the other root
+    flipped = bytearray(enc[:33])
+    flipped[32] ^= 0x80
+    o2, ok2 = eng.debug_decompress(bytes(flipped))
+    assert ok2[0] and (o2[0, :4] == pts[0, :4]).all() and (O.point_add(cv, o2[0], pts[0]) == 0).all()
+    # x values that are not on the curve, bad flags, x >= p, identity flag with x != 0
+    bad = []
+    x = 1
+    q = O.modulus(O.fid(cv, False))
+    while len(bad) < 5:
+        x += 1
+        b = x.to_bytes(32, "little") + b"\x00"
+        if O.point_deser_compressed(cv, b) is None:
+            bad.append(b)
+    bad += [enc[:32] + b"\xc0", enc[:32] + b"\x01", q.to_bytes(32, "little") + b"\x00", enc[:32] + b"\x40"]
+    o3, ok3 = eng.debug_decompress(b"".join(bad))
+    assert not ok3.any() and not o3.any()
+    for b in bad:
+        assert O.point_deser_compressed(cv, b) is None
