@@ -379,6 +379,21 @@ k_points_decompress(const u32* __restrict__ x_ark, const u32* __restrict__ flags
     store_words8(out_xy_ark + (size_t)i * 16 + 8, w + 8);
 }
 
+// gathers the selected points (ark layout) and writes them in the engine's resident layout
+template <class C> __global__ void k_points_gather_import(const u32* __restrict__ src_ark, const u32* __restrict__ idx, u32* __restrict__ dst, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[16];
+    const u32* p = src_ark + (size_t)idx[i] * 16;
+    load_words8(w, p);
+    load_words8(w + 8, p + 8);
+    Aff a = aff_load_ark<C>(w);
+    u32 o[16];
+    aff_store_dev(o, a);
+    store_words8(dst + (size_t)i * 16, o);
+    store_words8(dst + (size_t)i * 16 + 8, o + 8);
+}
+
 // ---- format conversion kernels -------------------------------------------------------------------
 // ark layout (x||y Montgomery R=2^256, identity = zeros) -> device layout (packed R' form)
 template <class C> __global__ void k_points_ark_to_dev(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {

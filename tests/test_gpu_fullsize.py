@@ -80,3 +80,14 @@ def test_msm_linearity_2pow20(eng):
     assert (eng.msm_dev(dbp, dsp, n) == a).all()
     for d in (db, ds, db1, ds1, ds2, dbp, dsp):
         d.free()
+
+
+def test_gpu_generator_derivation_matches_host_chain(eng):
+    """BulletproofGens::new on the GPU (device Tonelli-Shanks over the recorded ChaCha20 attempts) against the product's host
+    derivation of the same GeneratorsChain, deep into the chain (indices up to 2^16)"""
+    from ark_bulletproofs_amd import engine as E
+
+    G, H = eng.gens_download(1 << 16)
+    Gh = E.host_derive_generators(0, 0, 0, 1 << 16)
+    Hh = E.host_derive_generators(0, 1, 0, 1 << 16)
+    assert (G == Gh).all() and (H == Hh).all()
