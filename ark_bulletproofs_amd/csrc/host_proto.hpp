@@ -360,10 +360,13 @@ template <class C> struct ConstraintSystem {
         size_t n = num_vars;
         wL.assign(n, S::zero()); wR.assign(n, S::zero()); wO.assign(n, S::zero()); wV.assign(m, S::zero()); wc = S::zero();
         F4 ez = z;
+        const F4 one = S::one(), minus_one = S::neg(S::one());
         for (size_t q = 0; q + 1 < cs_off.size(); q++) {
+            const F4 nez = S::neg(ez);
             for (size_t k = cs_off[q]; k < cs_off[q + 1]; k++) {
                 const Term& t = cs_terms[k];
-                F4 p = S::mul(ez, t.c);
+                // most coefficients of real circuits are +-1: no multiplication needed for those
+                F4 p = t.c == one ? ez : t.c == minus_one ? nez : S::mul(ez, t.c);
                 switch (t.v.k) {
                     case VK_LEFT: wL[t.v.i] = S::add(wL[t.v.i], p); break;
                     case VK_RIGHT: wR[t.v.i] = S::add(wR[t.v.i], p); break;
