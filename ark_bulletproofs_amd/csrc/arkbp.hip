@@ -269,6 +269,99 @@ template <class S> static Naf naf_of(const F4& x) {
     return r;
 }
 
+// ---- GLV decomposition on the host (once per round: the fold scalar is uniform) ---------------------------------------
+// round(num / r) for a 512-bit num (8 limbs) and the 256-bit modulus r: binary long division, then round half up
+static void div_round_512(const uint64_t num[8], const uint64_t r[4], uint64_t quot[8]) {
+    uint64_t rem[5] = {0, 0, 0, 0, 0};
+    memset(quot, 0, 64);
+    auto geq = [&](const uint64_t* a /*5*/) { if (a[4]) return true; for (int i = 3; i >= 0; i--) { if (a[i] != r[i]) return a[i] > r[i]; } return true; };
+    auto sub = [&](uint64_t* a) { unsigned __int128 br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 t = (unsigned __int128)a[i] - r[i] - (uint64_t)br; a[i] = (uint64_t)t; br = (t >> 64) & 1; } a[4] -= (uint64_t)br; };
+    for (int bit = 511; bit >= 0; bit--) {
+        for (int i = 4; i > 0; i--) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 63);
+        rem[0] = (rem[0] << 1) | ((num[bit >> 6] >> (bit & 63)) & 1);
+        if (geq(rem)) { sub(rem); quot[bit >> 6] |= (uint64_t)1 << (bit & 63); }
+    }
+    // round: if 2*rem >= r, quot += 1
+    uint64_t dbl[5];
+    for (int i = 4; i > 0; i--) dbl[i] = (rem[i] << 1) | (rem[i - 1] >> 63);
+    dbl[0] = rem[0] << 1;
+    if (geq(dbl)) { for (int i = 0; i < 8; i++) if (++quot[i]) break; }
+}
+static void mul_256x192(const uint64_t a[4], const uint64_t b[3], uint64_t out[8]) {
+    memset(out, 0, 64);
+    for (int i = 0; i < 4; i++) {
+        unsigned __int128 c = 0;
+        for (int j = 0; j < 3; j++) { c += (unsigned __int128)a[i] * b[j] + out[i + j]; out[i + j] = (uint64_t)c; c >>= 64; }
+        for (int j = i + 3; j < 8 && c; j++) { c += out[j]; out[j] = (uint64_t)c; c >>= 64; }
+    }
+}
+// NAF digit masks of a non-negative integer < 2^160 given as 3 limbs; `negate` swaps the +1 / -1 masks
+static void naf_masks(const uint64_t k_in[3], bool negate, u32 plus[5], u32 minus[5]) {
+    uint64_t k[3] = {k_in[0], k_in[1], k_in[2]};
+    memset(plus, 0, 20); memset(minus, 0, 20);
+    for (int i = 0; i < 160; i++) {
+        if (!(k[0] | k[1] | k[2])) break;
+        if (k[0] & 1) {
+            const bool is_plus = (k[0] & 3) == 1;
+            if (is_plus) k[0] &= ~(uint64_t)1; else { for (int j = 0; j < 3; j++) if (++k[j]) break; }
+            u32* dst = (is_plus != negate) ? plus : minus;
+            dst[i >> 5] |= 1u << (i & 31);
+        }
+        k[0] = (k[0] >> 1) | (k[1] << 63); k[1] = (k[1] >> 1) | (k[2] << 63); k[2] >>= 1;
+    }
+}
+// t (field element) -> t1 + t2*lambda with short t1, t2; fills the four masks of one vector.  false if a half exceeds 129 bits.
+template <class C> static bool glv_decompose(const F4& t, u32 p1[5], u32 m1[5], u32 p2[5], u32 m2[5]) {
+    if constexpr (C::HAS_GLV) {
+        typedef host::Fld<typename C::Fr> S;
+        uint64_t tc[4]; S::to_canon(tc, t);
+        uint64_t prod[8], c1[8], c2[8];
+        mul_256x192(tc, C::GLV_B2, prod); div_round_512(prod, C::Fr::P64, c1);    // c1 = round(b2 * t / r)
+        mul_256x192(tc, C::GLV_NB1, prod); div_round_512(prod, C::Fr::P64, c2);   // c2 = round(-b1 * t / r)
+        auto small = [&](const uint64_t v[3]) { uint64_t c[4] = {v[0], v[1], v[2], 0}; return S::from_canon(c); };
+        const F4 fc1 = S::from_canon(c1), fc2 = S::from_canon(c2);   // c1, c2 < 2^130: the low 4 limbs hold them
+        // k2 = -c1*b1 - c2*b2 = c1*|b1| - c2*b2 ;  k1 = t - k2*lambda      (mod r; both are short up to sign)
+        F4 lam; memcpy(lam.v, C::LAMBDA64, 32);
+        const F4 k2 = S::sub(S::mul(fc1, small(C::GLV_NB1)), S::mul(fc2, small(C::GLV_B2)));
+        const F4 k1 = S::sub(t, S::mul(k2, lam));
+        auto split = [&](const F4& k, uint64_t mag[3], bool& neg) {
+            uint64_t c[4]; S::to_canon(c, k);
+            neg = false;
+            if (c[3] | (c[2] >> 1)) {   // not short: it is r - |k|
+                F4 nk = S::neg(k); S::to_canon(c, nk); neg = true;
+                if (c[3] | (c[2] >> 1)) return false;
+            }
+            mag[0] = c[0]; mag[1] = c[1]; mag[2] = c[2];
+            return true;
+        };
+        uint64_t mg1[3], mg2[3]; bool n1, n2;
+        if (!split(k1, mg1, n1) || !split(k2, mg2, n2)) return false;
+        naf_masks(mg1, n1, p1, m1);
+        naf_masks(mg2, n2, p2, m2);
+        return true;
+    } else {
+        (void)t; (void)p1; (void)m1; (void)p2; (void)m2;
+        return false;
+    }
+}
+template <class C> static bool glv_pair(const F4& tG, const F4& tH, Naf2& g, Naf2& h) {
+    return glv_decompose<C>(tG, g.p1, g.m1, g.p2, g.m2) && glv_decompose<C>(tH, h.p1, h.m1, h.p2, h.m2);
+}
+// launches the uniform fold for multipliers (tG, tH): GLV ladder where the curve has the endomorphism, plain NAF ladder otherwise
+template <class C> static void launch_uniform_fold(hipStream_t st, u32* d_G, u32* d_H, size_t n, const F4& tG, const F4& tH, int which) {
+    typedef host::Fld<typename C::Fr> S;
+    const u32 lanes = (u32)(which == 3 ? 2 * n : n);
+    if constexpr (C::HAS_GLV) {
+        Naf2 g, h;
+        if (glv_pair<C>(tG, tH, g, h)) {
+            hipLaunchKernelGGL(k_ipa_fold_glv<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, g, h, which);
+            return;
+        }
+    }
+    Naf a = naf_of<S>(tG), b = naf_of<S>(tH);
+    hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, a, b, which);
+}
+
 template <class C>
 static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b, size_t n,
                           const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4],
@@ -325,17 +418,16 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                 const int k = lg2(n);
                 const F4 s2 = S::mul(u, gf_halves[1]);
                 const F4 ginv = S::inv(gf_halves[1]);
-                Naf tG = naf_of<S>(S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)));
-                Naf tH = naf_of<S>(S::mul(S::mul(S::sqr(u), S::mul(gf_halves[0], ginv)), rho_pw[k]));
-                hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tH, 3);
+                launch_uniform_fold<C>(st, d_G, d_H, n, S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)),
+                                       S::mul(S::mul(S::sqr(u), S::mul(gf_halves[0], ginv)), rho_pw[k]), 3);
                 gamma_G = S::mul(gamma_G, s2);
                 gamma_H = S::mul(S::mul(ui, gf_halves[1]), rho_pw[32 + k]);
                 pending = true; h_geo = true;
             } else if (first && gf_halves && !gf_halves[0].is_zero() && !gf_halves[1].is_zero()) {
                 // G: u^-1*gL*G_L + u*gR*G_R = (u*gR) * (G_R + t*G_L), t = u^-1*gL / (u*gR): uniform, one NAF ladder; H: per-lane factors
                 const F4 s2 = S::mul(u, gf_halves[1]);
-                Naf tG = naf_of<S>(S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)));
-                hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tG, 1);
+                const F4 tG = S::mul(S::mul(ui, gf_halves[0]), S::inv(s2));
+                launch_uniform_fold<C>(st, d_G, d_H, n, tG, tG, 1);
                 hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u), words_of<S>(ui), 2);
                 gamma_G = S::mul(gamma_G, s2);
                 pending = true;
@@ -346,9 +438,7 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                 // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
                 // (geometric pending factor: c[i]/c[n+i] = rho^-n joins t, and K picks up rho^n)
                 const int k = lg2(n);
-                Naf tG = naf_of<S>(S::sqr(ui));
-                Naf tH = naf_of<S>(h_geo ? S::mul(S::sqr(u), rho_pw[k]) : S::sqr(u));
-                hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, (u32)n, tG, tH, 3);
+                launch_uniform_fold<C>(st, d_G, d_H, n, S::sqr(ui), h_geo ? S::mul(S::sqr(u), rho_pw[k]) : S::sqr(u), 3);
                 gamma_G = S::mul(gamma_G, u);
                 gamma_H = h_geo ? S::mul(S::mul(gamma_H, ui), rho_pw[32 + k]) : S::mul(gamma_H, ui);
                 pending = true;
@@ -829,6 +919,17 @@ int bp_ipa_verify(bp_ctx* c, size_t n, const uint64_t* G_factors, const uint64_t
     HIPCHK(hipSetDevice(c->device));
     return c->curve == 0 ? ipa_verify_host_entry<Secq>(c, n, G_factors, H_factors, P_xy, Q_xy, G_xy, H_xy, L_xy, R_xy, lg_n, challenges, a, b)
                          : ipa_verify_host_entry<Zorro>(c, n, G_factors, H_factors, P_xy, Q_xy, G_xy, H_xy, L_xy, R_xy, lg_n, challenges, a, b);
+}
+
+// test hook (host only): the GLV split of the uniform fold multiplier t (ark words): masks = p1[5] m1[5] p2[5] m2[5],
+// t = sum (p1-m1)_i 2^i + lambda * sum (p2-m2)_i 2^i (mod r).  BP_E_ARG for a curve without the endomorphism.
+int bp_debug_glv_decompose(int curve, const uint64_t t[4], uint32_t masks[20], uint64_t lambda_out[4]) {
+    if (curve != 0 || !t || !masks || !lambda_out) return BP_E_ARG;
+    F4 x; memcpy(x.v, t, 32);
+    if (!glv_decompose<Secq>(x, masks, masks + 5, masks + 10, masks + 15)) { g_err = "glv_decompose: half longer than 129 bits"; return BP_E_ARG; }
+    F4 lam; memcpy(lam.v, Secq::LAMBDA64, 32);
+    host::Fld<Secq::Fr>::to_canon(lambda_out, lam);
+    return BP_OK;
 }
 
 int bp_debug_decompress(bp_ctx* c, const uint8_t* compressed33, size_t n, uint64_t* out_xy, uint32_t* out_ok) {

@@ -261,4 +261,45 @@ k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf 
     store_words8(V + (size_t)i * 16 + 8, w + 8);
 }
 
+// GLV variant of the uniform fold for curves with the j = 0 endomorphism phi(x, y) = (beta*x, y) = [lambda](x, y) (secq256k1):
+// t = t1 + t2*lambda with |t1|, |t2| < 2^129 (host-side lattice decomposition, signs folded into the digit masks), so
+// t*P1 = t1*P1 + t2*phi(P1) needs 129 doublings instead of 256.  Same contract as k_ipa_fold_uniform otherwise.
+struct Naf2 {
+    u32 p1[5], m1[5], p2[5], m2[5];   // bit i: digit +1 / -1 at 2^i of t1 (p1/m1) and t2 (p2/m2), 130 digits
+};
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH, int which /* 1: G only, 2: H only, 3: both */) {
+    typedef typename C::Fq F;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (which == 3 ? 2 * n : n)) return;
+    const bool isH = which == 2 || (which == 3 && t >= n);
+    const u32 i = (which == 3 && isH) ? t - n : t;
+    u32* V = isH ? H : G;
+    const Aff P1 = load_aff_dev(V + (size_t)i * 16), P2 = load_aff_dev(V + (size_t)(n + i) * 16);
+    Aff Q1;   // phi(P1); the identity (0,0) maps to itself
+    Q1.x = fe_canon<F>(fe_mul<F>(P1.x, fe_const<F, C::BETA29>()));
+    Q1.y = P1.y;
+    const Aff N1 = aff_cneg_lazy<C>(P1, true), NQ1 = aff_cneg_lazy<C>(Q1, true);
+    Jac acc = jac_inf<C>();
+#pragma unroll 1
+    for (int wd = 4; wd >= 0; wd--) {
+        const u32 a = isH ? tH.p1[wd] : tG.p1[wd], b = isH ? tH.m1[wd] : tG.m1[wd];
+        const u32 c = isH ? tH.p2[wd] : tG.p2[wd], d = isH ? tH.m2[wd] : tG.m2[wd];
+#pragma unroll 1
+        for (int bit = (wd == 4 ? 1 : 31); bit >= 0; bit--) {
+            acc = jac_dbl<C>(acc);
+            if ((a >> bit) & 1) acc = jac_madd<C>(acc, P1);
+            else if ((b >> bit) & 1) acc = jac_madd<C>(acc, N1);
+            if ((c >> bit) & 1) acc = jac_madd<C>(acc, Q1);
+            else if ((d >> bit) & 1) acc = jac_madd<C>(acc, NQ1);
+        }
+    }
+    acc = jac_madd<C>(acc, P2);
+    const Aff o = jac_to_aff<C>(acc);
+    u32 w[16];
+    aff_store_dev(w, o);
+    store_words8(V + (size_t)i * 16, w);
+    store_words8(V + (size_t)i * 16 + 8, w + 8);
+}
+
 }  // namespace arkbp

@@ -189,6 +189,10 @@ int bp_debug_field_op(bp_ctx* ctx, int field, int op, const uint64_t* a, const u
 /* ark-serialize compressed SW points (33 bytes each: x LE || flag byte) -> affine, on the GPU (the square roots of
  * `R1CSProof::from_bytes`, src/r1cs/proof.rs:83-91); out_ok[i] = 0 for malformed or off-curve encodings */
 int bp_debug_decompress(bp_ctx* ctx, const uint8_t* compressed33, size_t n, uint64_t* out_xy, uint32_t* out_ok);
+/* host only: GLV split of a fold multiplier t (ark words, curve 0 only): masks = p1[5] m1[5] p2[5] m2[5] signed-digit bit masks
+ * with t = t1 + lambda*t2 (mod r); lambda_out = canonical lambda.  The uniform IPA fold (src/inner_product_proof.rs:139-150)
+ * runs its ladder over these 130-digit halves on secq256k1. */
+int bp_debug_glv_decompose(int curve, const uint64_t t[4], uint32_t masks[20], uint64_t lambda_out[4]);
 /* op: 0 P+Q (general add), 1 P+Q (mixed add), 2 2P, 3 k*P (k canonical, one per element) */
 int bp_debug_point_op(bp_ctx* ctx, int op, const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* k, uint64_t* out_xy, size_t n);
 

@@ -82,3 +82,45 @@ def test_product_transcript_rng_scalar_and_x8(E, oracle, curve):
     if got8 is None:
         pytest.skip("no AVX-512 on this host: the x8 path is not taken")
     assert (got8 == exp).all()
+
+
+def test_product_glv_decomposition():
+    """Host-side GLV split used by the uniform IPA fold on secq256k1: t = t1 + lambda*t2 (mod r), both halves given as
+    non-adjacent signed digits of at most 130 positions; lambda is a primitive cube root of unity in Fr."""
+    import ctypes as C
+    import random
+
+    from ark_bulletproofs_amd import _lib
+
+    L = _lib.lib()
+    r = 2**256 - 2**32 - 977   # secq256k1 scalar field = secp256k1 base field
+    R = pow(2, 256, r)
+    rnd = random.Random(7)
+    samples = [0, 1, 2, r - 1, r - 2, (r - 1) // 2, 2**128, 2**129 - 1] + [rnd.randrange(r) for _ in range(300)]
+    lam = None
+    for t in samples:
+        tm = np.array([((t * R % r) >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+        masks = np.zeros(20, dtype=np.uint32)
+        lam_out = np.zeros(4, dtype=np.uint64)
+        rc = L.bp_debug_glv_decompose(0, _lib.ptr(tm), _lib.ptr(masks), _lib.ptr(lam_out))
+        assert rc == 0
+        lam_t = sum(int(lam_out[i]) << (64 * i) for i in range(4))
+        if lam is None:
+            lam = lam_t
+            assert lam != 1 and pow(lam, 3, r) == 1
+        assert lam_t == lam
+
+        def val(plus, minus):
+            p = sum(int(plus[i]) << (32 * i) for i in range(5))
+            m = sum(int(minus[i]) << (32 * i) for i in range(5))
+            assert p & m == 0 and (p | m) < 2**130
+            nz = p | m
+            assert nz & (nz >> 1) == 0   # non-adjacent
+            return p - m
+
+        t1 = val(masks[0:5], masks[5:10])
+        t2 = val(masks[10:15], masks[15:20])
+        assert abs(t1) < 2**129 and abs(t2) < 2**129
+        assert (t1 + lam * t2 - t) % r == 0
+    masks = np.zeros(20, dtype=np.uint32)
+    assert L.bp_debug_glv_decompose(1, _lib.ptr(tm), _lib.ptr(masks), _lib.ptr(lam_out)) != 0   # zorro: no endomorphism
