@@ -15,6 +15,7 @@
 #include <chrono>
 #include "host_proto.hpp"
 #include "r1cs.cuh"
+#include "pedersen.cuh"
 
 using namespace arkbp;
 using arkbp::host::A4;
@@ -65,11 +66,12 @@ struct bp_ctx {
     KTimer timers[BP_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // MSM workspaces
-    DevBuf canon, hist, lvl_off, totals, cursor, entries, slots, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
+    DevBuf canon, hist, lvl_off, totals, cursor, entries, slots, bin_cur, boff, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
     // IPA workspaces (resident layouts)
     DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q;
     // generator tables (BulletproofGens party 0, PedersenGens), resident layout
     DevBuf d_G, d_H, d_pc;
+    DevBuf pc_table;   // fixed-base window tables of B, B_blinding (pedersen.cuh), built on first use
     size_t gens_cap = 0;
     A4 pc_B, pc_Bb;
     // R1CS prover / verifier vectors (resident scalar layout)
@@ -152,37 +154,93 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         HIPCHK(hipHostMalloc((void**)&ctx->h_T, tbytes + 4096));
         ctx->h_T_cap = tbytes + 4096;
     }
-    // slot plan of the one-pass sort
-    SlotPlan sp; memset(&sp, 0, sizeof sp);
-    size_t nslots = 0;
+    // slot plan of the one-pass sort; two-level (binned) sort for large MSMs: the full windows go to bin regions, the short
+    // top window keeps its slots behind them
     if (pl.W > MSM_MAXW) { g_err = "msm: too many windows"; return BP_E_ARG; }
-    for (int w = 0; w < pl.W; w++) {
-        const int bits_left = C::Fr::BITS - pl.c * w;  // scalar bits at or above this window's base
-        size_t nb_eff = (size_t)pl.NB;
-        if (bits_left < pl.c - 1) nb_eff = std::min<size_t>(nb_eff, ((size_t)1 << std::max(bits_left, 0)) + 1);
-        size_t cap = std::min<size_t>(n, 2 * ((n + nb_eff - 1) / nb_eff) + 32);
-        sp.base[w] = (u32)nslots; sp.cap[w] = (u32)cap;
-        nslots += nb_eff * cap;
+    BinPlan bp; memset(&bp, 0, sizeof bp);
+    bool binned = false;
+    {
+        const int bits_last = C::Fr::BITS - pl.c * (pl.W - 1);
+        const int wbn = bits_last < pl.c - 1 ? pl.W - 1 : pl.W;
+        static const bool no_bins = getenv("ARKBP_MSM_NOBIN") != nullptr;
+        if (n >= 4096 && wbn > 0 && !no_bins) {
+            u32 nbin = 1, lg = 0;
+            while ((size_t)nbin * 8192 < n && nbin < (u32)pl.NB) { nbin <<= 1; lg++; }
+            int LB = pl.c - 1 - (int)lg;
+            while (LB > 11) { nbin <<= 1; LB--; }
+            const double mu = (double)n / nbin;
+            const size_t cap = std::min<size_t>(n, (size_t)(mu + 8.0 * std::sqrt(mu) + 64.0));
+            const size_t lds_sort = (((size_t)1 << LB) + 4 + cap) * 4;
+            if (n < ((size_t)1 << (31 - LB)) && lds_sort <= 64 * 1024 && (size_t)wbn * nbin * cap < ((size_t)1 << 31)) {
+                bp.LB = (u32)LB; bp.NBIN = nbin; bp.cap = (u32)cap; bp.wb = (u32)wbn;
+                static const int tpt_env = getenv("ARKBP_MSM_TPT") ? atoi(getenv("ARKBP_MSM_TPT")) : 0;
+                bp.tpt = tpt_env > 0 ? (u32)tpt_env : (u32)std::min<size_t>(16, std::max<size_t>(1, n / (256 * 512)));
+                if (wbn < pl.W) {   // same-address device atomics serialise (~170 ns each): count a narrow top window per workgroup
+                    const size_t nb_top = std::min<size_t>((size_t)pl.NB, ((size_t)1 << std::max(bits_last, 0)) + 1);
+                    if (nb_top <= 2048) bp.top_nb = (u32)nb_top;
+                }
+                binned = true;
+            }
+        }
     }
-    if (nslots >= ((size_t)1 << 32)) { g_err = "msm: slot array too large"; return BP_E_ARG; }
-    BPCHK(ctx->slots.ensure(nslots * 4));
+    auto make_slots = [&](SlotPlan& sp, int w_first, size_t first_slot) -> size_t {
+        memset(&sp, 0, sizeof sp);
+        size_t nslots = first_slot;
+        for (int w = w_first; w < pl.W; w++) {
+            const int bits_left = C::Fr::BITS - pl.c * w;  // scalar bits at or above this window's base
+            size_t nb_eff = (size_t)pl.NB;
+            if (bits_left < pl.c - 1) nb_eff = std::min<size_t>(nb_eff, ((size_t)1 << std::max(bits_left, 0)) + 1);
+            size_t cap = std::min<size_t>(n, 2 * ((n + nb_eff - 1) / nb_eff) + 32);
+            sp.base[w] = (u32)nslots; sp.cap[w] = (u32)cap;
+            nslots += nb_eff * cap;
+        }
+        return nslots;
+    };
+    SlotPlan sp;
     ScopedK total(ctx, BP_K_MSM_TOTAL);
     u32* lvl = ctx->lvl_off.as<u32>();
     u32* d_tot = ctx->totals.as<u32>();
     u32* d_tiles = d_tot + (NL + 2);
     u32* d_over = d_tot + (NL + 1);
-    HIPCHK(hipMemsetAsync(ctx->hist.p, 0, pl.B * 4, st));
-    HIPCHK(hipMemsetAsync(d_over, 0, 4, st));
     const int TB = 256;
     const u32 gb = (u32)((n + TB - 1) / TB);
-    hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont, sp,
-                       ctx->slots.as<u32>(), d_over);
-    hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl);
-    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
-    hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl);
-    HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
+    // front end: digits, histogram, placement, scans; leaves the totals (and the overflow flag) in h_totals
+    auto front_end = [&](bool bins) -> int {
+        const size_t nslots = make_slots(sp, bins ? (int)bp.wb : 0, bins ? (size_t)bp.wb * bp.NBIN * bp.cap : 0);
+        if (nslots >= ((size_t)1 << 32)) { g_err = "msm: slot array too large"; return BP_E_ARG; }
+        BPCHK(ctx->slots.ensure(nslots * 4));
+        HIPCHK(hipMemsetAsync(ctx->hist.p, 0, pl.B * 4, st));
+        HIPCHK(hipMemsetAsync(d_over, 0, 4, st));
+        if (bins) {
+            BPCHK(ctx->bin_cur.ensure((size_t)pl.W * bp.NBIN * 4));
+            BPCHK(ctx->boff.ensure((size_t)pl.B * 4));
+            HIPCHK(hipMemsetAsync(ctx->bin_cur.p, 0, (size_t)pl.W * bp.NBIN * 4, st));
+            const int wg = std::max(1, (int)(12288 / bp.NBIN));   // windows per launch: 48 KiB of LDS counters
+            const u32 gp = (u32)((n + (size_t)256 * bp.tpt - 1) / ((size_t)256 * bp.tpt));
+            for (int wa = 0; wa < (int)bp.wb; wa += wg) {
+                const int we = std::min<int>((int)bp.wb, wa + wg);
+                hipLaunchKernelGGL(k_msm_bin_partition<C>, dim3(gp), dim3(256), ((size_t)(we - wa) * bp.NBIN + (wa == 0 ? bp.top_nb : 0)) * 4, st, d_scalars, ctx->canon.as<u32>(),
+                                   ctx->hist.as<u32>(), pl, scalars_mont, bp, sp, ctx->bin_cur.as<u32>(), ctx->slots.as<u32>(), d_over, wa, we, wa == 0 ? 1 : 0);
+            }
+            hipLaunchKernelGGL(k_msm_bin_sort, dim3(bp.NBIN, pl.W), dim3(256), (((size_t)1 << bp.LB) + 4 + bp.cap) * 4, st, ctx->slots.as<u32>(),
+                               ctx->bin_cur.as<u32>(), ctx->hist.as<u32>(), ctx->boff.as<u32>(), pl, bp, sp);
+        } else {
+            hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont, sp,
+                               ctx->slots.as<u32>(), d_over);
+        }
+        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl);
+        hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
+        hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl);
+        HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        return BP_OK;
+    };
+    BPCHK(front_end(binned));
+    if (binned && ctx->h_totals[NL + 1] != 0) {   // a bin region overflowed (skewed scalars): one-pass slots for every window
+        binned = false;
+        BPCHK(front_end(false));
+    }
     const bool slotted = ctx->h_totals[NL + 1] == 0;
     const u32* entries_ptr = ctx->slots.as<u32>();
     if (!slotted) {  // some bucket outgrew its slots (skewed scalars): exact counting-sort scatter
@@ -203,7 +261,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     {
         ScopedK acc(ctx, BP_K_MSM_ACCUM);
         hipLaunchKernelGGL(k_msm_accum<C>, dim3((tot[1] + TB - 1) / TB), dim3(TB), 0, st, segs, entries_ptr, lvl, lvl + Bp1, ctx->lvA.as<u32>(), pl.B,
-                           tot[1], slotted ? 1 : 0, sp, (u32)pl.NB);
+                           tot[1], slotted ? (binned ? 2 : 1) : 0, sp, (u32)pl.NB, ctx->boff.as<u32>());
     }
     u32* cur = ctx->lvA.as<u32>();
     u32* nxt = ctx->lvB.as<u32>();
@@ -583,11 +641,12 @@ struct bp_stmt {
     bool consumed = false;
     bp_stmt(int sc, const uint8_t* seed) : scenario(sc), tr(host::scenario_label(sc)), prng(seed) {}
 };
-template <class C> static int stmt_build(bp_stmt* s, std::unique_ptr<host::ConstraintSystem<C>>& cs, const uint64_t* params) {
+template <class C> static int stmt_build(bp_stmt* s, std::unique_ptr<host::ConstraintSystem<C>>& cs, const uint64_t* params, bp_ctx* ctx = nullptr) {
     cs.reset(new host::ConstraintSystem<C>());
     cs->tr = &s->tr; cs->proving = true;
     host::TP<C>::r1cs_domain_sep(s->tr);
     host::PedersenGens<C> pc = host::PedersenGens<C>::make_default();
+    if (ctx) pedersen_attach<C>(ctx, pc);
     return host::scenario_prover<C>(*cs, pc, s->prng, s->scenario, params, s->io);
 }
 
@@ -618,9 +677,9 @@ void bp_ctx_destroy(bp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
+    DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q,
-                      &c->d_G, &c->d_H, &c->d_pc, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
+                      &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
                       &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart};
     c->templates.clear();
     for (auto b : bufs) b->release();
@@ -846,6 +905,22 @@ int bp_stmt_prover_create(int curve, int scenario, const uint64_t* params, const
     if (rc) { delete s; return rc; }
     *out = s;
     return BP_OK;
+}
+// as bp_stmt_prover_create, with the statement's Pedersen commitments computed on ctx's GPU in one batch
+int bp_stmt_prover_create_dev(bp_ctx* c, int scenario, const uint64_t* params, const uint8_t seed[32], bp_stmt** out) {
+    if (!c || !params || !seed || !out) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    bp_stmt* s = new bp_stmt(scenario, seed);
+    s->curve = c->curve;
+    int rc = c->curve == 0 ? stmt_build<Secq>(s, s->cs0, params, c) : stmt_build<Zorro>(s, s->cs1, params, c);
+    if (rc) { delete s; return rc; }
+    *out = s;
+    return BP_OK;
+}
+int bp_pedersen_commit_batch(bp_ctx* c, const uint64_t* v, const uint64_t* blind, size_t m, uint64_t* out_xy) {
+    if (!c || (m && (!v || !blind || !out_xy))) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? pedersen_commit_batch<Secq>(c, v, blind, m, out_xy) : pedersen_commit_batch<Zorro>(c, v, blind, m, out_xy);
 }
 void bp_stmt_free(bp_stmt* s) { delete s; }
 int bp_stmt_info(bp_stmt* s, uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, size_t* multipliers, size_t* constraints) {

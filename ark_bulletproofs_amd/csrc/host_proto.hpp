@@ -220,6 +220,13 @@ template <class C> struct PedersenGens {
     A4 commit(const F4& v, const F4& blind) const {  // src/generators.rs:39-44
         return Grp<C>::to_aff(Grp<C>::add(Grp<C>::mul(B, v), Grp<C>::mul(B_blinding, blind)));
     }
+    // optional: all commitments of a statement in one call (the engine installs its GPU fixed-base kernel here)
+    std::function<int(const F4* v, const F4* blind, size_t m, A4* out)> batch;
+    int commit_many(const F4* v, const F4* blind, size_t m, A4* out) const {
+        if (batch && m > 1) return batch(v, blind, m, out);
+        for (size_t i = 0; i < m; i++) out[i] = commit(v[i], blind[i]);
+        return BP_OK;
+    }
 };
 
 // GeneratorsChain (src/generators.rs:71-121) for label 'G'|'H' || LE32(party).  The ChaCha20 word stream is
@@ -435,16 +442,34 @@ template <class C> static int scenario_prover(ConstraintSystem<C>& cs, const Ped
         io.commitments.push_back(Vp);
         return Var{VK_COMMITTED, i};
     };
+    // a run of Prover::commit calls whose points do not depend on each other: the group work is one batch, the transcript
+    // appends and variable numbering keep the reference's order
+    auto commit_many = [&](const std::vector<F4>& vals, const std::vector<F4>& blinds, std::vector<Var>& vars) -> int {
+        std::vector<A4> pts(vals.size());
+        int rc = pc.commit_many(vals.data(), blinds.data(), vals.size(), pts.data());
+        if (rc) return rc;
+        vars.resize(vals.size());
+        for (size_t i = 0; i < vals.size(); i++) {
+            u32 idx = (u32)cs.v.size();
+            cs.v.push_back(vals[i]); cs.v_blinding.push_back(blinds[i]);
+            TP<C>::append_point(*cs.tr, "V", pts[i]);
+            io.commitments.push_back(pts[i]);
+            vars[i] = Var{VK_COMMITTED, idx};
+        }
+        return BP_OK;
+    };
     switch (sc) {
         case SC_SHUFFLE: {
             size_t k = prm[0];
-            std::vector<F4> in(k), out(k);
+            std::vector<F4> in(k), out(k), bl(k);
             for (auto& x : in) x = S::from_u64(prng.next_u64());
             for (size_t i = 0; i < k; i++) out[i] = in[(i + 1) % k];
             cs.tr->append_message("dom-sep", "ShuffleProof"); cs.tr->append_u64("k", k);
-            std::vector<Var> xv(k), yv(k);
-            for (size_t i = 0; i < k; i++) { F4 b = rand_fe<FrP>(prng); xv[i] = commit(in[i], b); }
-            for (size_t i = 0; i < k; i++) { F4 b = rand_fe<FrP>(prng); yv[i] = commit(out[i], b); }
+            std::vector<Var> xv, yv;
+            for (size_t i = 0; i < k; i++) bl[i] = rand_fe<FrP>(prng);
+            int rc = commit_many(in, bl, xv); if (rc) return rc;
+            for (size_t i = 0; i < k; i++) bl[i] = rand_fe<FrP>(prng);
+            rc = commit_many(out, bl, yv); if (rc) return rc;
             return shuffle_gadget<C>(cs, xv, yv);
         }
         case SC_RANGE: {
@@ -476,13 +501,18 @@ template <class C> static int scenario_prover(ConstraintSystem<C>& cs, const Ped
         }
         case SC_MULTI_RANGE: {
             size_t count = prm[0], nbits = prm[1];
-            for (size_t j = 0; j < count; j++) {
+            std::vector<u64> raw(count);
+            std::vector<F4> vals(count), bl(count);
+            for (size_t j = 0; j < count; j++) {   // the gadget draws nothing and appends nothing in phase 1: commits can go first
                 u64 val = prng.next_u64();
                 if (nbits < 64) val &= (((u64)1 << nbits) - 1);
                 if (prm[2] && j == count - 1) val = nbits < 64 ? ((u64)1 << nbits) : val;
-                F4 b = rand_fe<FrP>(prng);
-                Var var = commit(S::from_u64(val), b);
-                int rc = range_gadget<C>(cs, cs.lc_var(var), &val, nbits);
+                raw[j] = val; vals[j] = S::from_u64(val); bl[j] = rand_fe<FrP>(prng);
+            }
+            std::vector<Var> vars;
+            int rc = commit_many(vals, bl, vars); if (rc) return rc;
+            for (size_t j = 0; j < count; j++) {
+                rc = range_gadget<C>(cs, cs.lc_var(vars[j]), &raw[j], nbits);
                 if (rc) return rc;
             }
             return BP_OK;

@@ -167,6 +167,142 @@ k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __re
     }
 }
 
+// 1b. Two-level sort for large MSMs.  Returning device-scope atomics run at the memory side on this multi-XCD part
+// (~6 G/s measured), and k_msm_digits issues one per (term, window).  Here a workgroup first counts its tile of terms per
+// coarse BIN (the top bits of |digit|-1) in LDS, reserves room in each bin's region with ONE global atomic per (window, bin),
+// and places its entries; k_msm_bin_sort then sorts every bin region by the remaining LB bucket bits inside LDS and emits
+// the per-bucket population (hist) and start (boff) with plain stores.  Bin regions have fixed capacity (mean + 8 sigma);
+// an overflow flags the MSM for the exact path.  The short top window (few distinct digits) keeps the slot scheme.
+struct BinPlan {
+    u32 LB;      // bucket bits resolved inside a bin
+    u32 NBIN;    // bins per window = NB >> LB
+    u32 cap;     // entries per bin region
+    u32 wb;      // windows [0, wb) are binned; [wb, W) use SlotPlan
+    u32 tpt;     // terms per lane in k_msm_bin_partition
+    u32 top_nb;  // > 0: the slot window has this many possible buckets (<= 2048) and is counted per workgroup in LDS
+};
+// entry in a bin region: (term << (LB+1)) | (fine bucket << 1) | sign
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_bin_partition(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont, BinPlan bp,
+                    SlotPlan sp, u32* __restrict__ bin_cur, u32* __restrict__ ent, u32* __restrict__ overflow, int wa, int we, int first) {
+    typedef typename C::Fr Fr;
+    extern __shared__ u32 lds_cnt[];   // (we - wa) * NBIN bin counters, then top_nb bucket counters of the slot window
+    const u32 nbinc = (u32)(we - wa) * bp.NBIN;
+    const bool top = first && bp.top_nb;           // this launch also places the slot window, aggregated per workgroup
+    const u32 ncnt = nbinc + (top ? bp.top_nb : 0u);
+    u32* lds_top = lds_cnt + nbinc;
+    const int wtop = pl.W - 1;
+    for (u32 x = threadIdx.x; x < ncnt; x += 256) lds_cnt[x] = 0;
+    __syncthreads();
+    const u32 tile0 = blockIdx.x * 256u * bp.tpt;
+    const int wend = top ? pl.W : we;
+    for (u32 t = 0; t < bp.tpt; t++) {
+        const u32 i = tile0 + t * 256u + threadIdx.x;
+        if (i >= pl.n) break;
+        u32 k[8];
+        load_words8(k, scalars + (size_t)i * 8);
+        if (scalars_mont == 1) { Fe s = fe_load_ark<Fr>(k); fe_store_canon<Fr>(k, s); }
+        else if (scalars_mont == 2) { Fe s = fe_unpack(k); fe_store_canon<Fr>(k, s); }
+        if (first) store_words8(canon + (size_t)i * 8, k);
+        u32 carry = 0;
+        for (int w = 0; w < wend; w++) {
+            const int d = msm_digit(k, w, pl.c, carry);
+            if (d == 0 || w < pl.w_lo || w >= pl.w_hi) continue;
+            const u32 v = (u32)(d < 0 ? -d : d) - 1;
+            if (w >= (int)bp.wb) { if (top && v < bp.top_nb) atomicAdd(&lds_top[v], 1u); }
+            else if (w >= wa && w < we) atomicAdd(&lds_cnt[(u32)(w - wa) * bp.NBIN + (v >> bp.LB)], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 x = threadIdx.x; x < ncnt; x += 256) {
+        const u32 cn = lds_cnt[x];
+        if (cn) lds_cnt[x] = x < nbinc ? atomicAdd(&bin_cur[(u32)wa * bp.NBIN + x], cn) : atomicAdd(&hist[(u32)wtop * pl.NB + (x - nbinc)], cn);
+    }
+    __syncthreads();
+    const u32 fmask = (1u << bp.LB) - 1u;
+    for (u32 t = 0; t < bp.tpt; t++) {
+        const u32 i = tile0 + t * 256u + threadIdx.x;
+        const bool live = i < pl.n;   // no early exit: wave_count below is a wave-wide operation
+        u32 k[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) k[j] = 0;
+        if (live) load_words8(k, canon + (size_t)i * 8);
+        u32 carry = 0;
+        for (int w = 0; w < pl.W; w++) {
+            const int d = msm_digit(k, w, pl.c, carry);
+            const bool valid = live && d != 0 && w >= pl.w_lo && w < pl.w_hi;
+            const u32 v = (u32)(d < 0 ? -d : d) - 1;
+            if (w >= (int)bp.wb) {          // slot scheme (only in the launch that owns the first window group)
+                if (!first) continue;
+                u32 pos;
+                if (bp.top_nb) pos = valid ? atomicAdd(&lds_top[min(v, bp.top_nb - 1u)], 1u) : 0u;
+                else pos = wave_count(hist, (u32)w * pl.NB + v, valid);
+                if (valid) {
+                    if (pos < sp.cap[w]) ent[sp.base[w] + v * sp.cap[w] + pos] = (i << 1) | (d < 0 ? 1u : 0u);
+                    else *overflow = 1u;
+                }
+            } else if (valid && w >= wa && w < we) {
+                const u32 bin = v >> bp.LB;
+                const u32 pos = atomicAdd(&lds_cnt[(u32)(w - wa) * bp.NBIN + bin], 1u);
+                if (pos < bp.cap) ent[((size_t)w * bp.NBIN + bin) * bp.cap + pos] = (i << (bp.LB + 1)) | ((v & fmask) << 1) | (d < 0 ? 1u : 0u);
+                else *overflow = 1u;
+            }
+        }
+    }
+}
+// grid (NBIN, W).  Binned window: sort the bin region by fine bucket in LDS; write hist and boff for its 2^LB buckets and the
+// entries back as (term << 1) | sign.  Slot window: boff only (hist was counted by k_msm_bin_partition's atomics).
+__global__ void __launch_bounds__(256)
+k_msm_bin_sort(u32* __restrict__ ent, const u32* __restrict__ bin_cur, u32* __restrict__ hist, u32* __restrict__ boff, MsmPlan pl, BinPlan bp,
+               SlotPlan sp) {
+    extern __shared__ u32 lds[];
+    const u32 w = blockIdx.y, bin = blockIdx.x, tid = threadIdx.x;
+    if (w >= bp.wb) {
+        for (u32 v = bin * 256u + tid; v < (u32)pl.NB; v += bp.NBIN * 256u) boff[w * pl.NB + v] = sp.base[w] + v * sp.cap[w];
+        return;
+    }
+    const u32 NF = 1u << bp.LB;
+    u32* cnt = lds;            // NF counters, then cursors
+    u32* wsum = lds + NF;      // 4 wave sums
+    u32* buf = lds + NF + 4;   // cap entries
+    const size_t region = ((size_t)w * bp.NBIN + bin) * bp.cap;
+    const u32 n = min(bin_cur[w * bp.NBIN + bin], bp.cap);
+    for (u32 x = tid; x < NF; x += 256) cnt[x] = 0;
+    __syncthreads();
+    const u32 fmask = NF - 1u;
+    for (u32 x = tid; x < n; x += 256) {
+        const u32 e = ent[region + x];
+        buf[x] = e;
+        atomicAdd(&cnt[(e >> 1) & fmask], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..NF): lane t owns the contiguous run [t*per, (t+1)*per)
+    const u32 per = (NF + 255u) / 256u;
+    u32 run = 0;
+    for (u32 x = tid * per; x < min((tid + 1) * per, NF); x++) run += cnt[x];
+    u32 incl = run;
+    const u32 lane = tid & 63u, wv = tid >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const u32 t2 = __shfl_up(incl, o); if ((int)lane >= o) incl += t2; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    u32 excl = incl - run;
+    for (u32 q = 0; q < wv; q++) excl += wsum[q];
+    const u32 b0 = w * pl.NB + (bin << bp.LB);
+    for (u32 x = tid * per; x < min((tid + 1) * per, NF); x++) {
+        const u32 cn = cnt[x];
+        hist[b0 + x] = cn;
+        boff[b0 + x] = (u32)region + excl;
+        cnt[x] = excl;        // becomes the placement cursor
+        excl += cn;
+    }
+    __syncthreads();
+    for (u32 x = tid; x < n; x += 256) {
+        const u32 e = buf[x];
+        const u32 pos = atomicAdd(&cnt[(e >> 1) & fmask], 1u);
+        ent[region + pos] = ((e >> (bp.LB + 1)) << 1) | (e & 1u);
+    }
+}
+
 // 2. scans.  lvl_off[k] (k = 0..nl-1) has B+1 entries: level 0 counts entries, level k >= 1 counts
 // ceil(cnt / CH^k) chunks.  totals[k] = lvl_off[k][B]; totals[NLMAX] = max bucket population.
 // Three launches: per-tile sums, one-workgroup scan of the tile sums, per-tile exclusive scan.
@@ -273,12 +409,15 @@ __device__ __forceinline__ u32 find_bucket(const u32* __restrict__ off, u32 B, u
 // 4. level 1: lane j sums the j-th CH-entry chunk (mixed adds of gathered affine bases)
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restrict__ off0, const u32* __restrict__ off1, u32* __restrict__ out,
-            u32 B, u32 nchunks, int slotted, SlotPlan sp, u32 NB) {
+            u32 B, u32 nchunks, int slotted, SlotPlan sp, u32 NB, const u32* __restrict__ boff) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nchunks) return;
     const u32 b = find_bucket(off1, B, j);
     u32 beg, end;
-    if (slotted) {  // entries = slot array; the bucket's population is off0[b+1] - off0[b]
+    if (slotted == 2) {  // two-level sort: bucket b starts at boff[b]; its population is off0[b+1] - off0[b]
+        beg = boff[b] + (j - off1[b]) * MSM_CH;
+        end = min(beg + MSM_CH, boff[b] + (off0[b + 1] - off0[b]));
+    } else if (slotted) {  // entries = slot array; the bucket's population is off0[b+1] - off0[b]
         const u32 w = b / NB, v = b - w * NB;
         const u32 s0 = sp.base[w] + v * sp.cap[w];
         beg = s0 + (j - off1[b]) * MSM_CH;

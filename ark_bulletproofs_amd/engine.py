@@ -315,11 +315,17 @@ def host_points_sum(curve, pts_xy):
 
 # ---- statements (setup separated from prove(), several proofs in flight) -----------------------------------
 class Statement:
-    """Prover::new + commits + gadget for a scenario (host only).  prove(engine) consumes it."""
+    """Prover::new + commits + gadget for a scenario.  Host only by default; with `engine` the statement's Pedersen
+    commitments are one GPU batch (same statement either way).  prove(engine) consumes it."""
 
-    def __init__(self, curve, scenario, params, seed):
+    def __init__(self, curve, scenario, params, seed, engine=None):
         self.h = C.c_void_p()
-        check(lib().bp_stmt_prover_create(curve, scenario, ptr(_prm(params)), bytes(seed), C.byref(self.h)), "bp_stmt_prover_create")
+        if engine is not None:
+            if engine.curve != curve:
+                raise ValueError("Statement: engine curve differs")
+            check(lib().bp_stmt_prover_create_dev(engine.ctx, scenario, ptr(_prm(params)), bytes(seed), C.byref(self.h)), "bp_stmt_prover_create_dev")
+        else:
+            check(lib().bp_stmt_prover_create(curve, scenario, ptr(_prm(params)), bytes(seed), C.byref(self.h)), "bp_stmt_prover_create")
         self.curve = curve
 
     def info(self, m_cap=1 << 16):
@@ -352,6 +358,16 @@ class Statement:
             pass
 
 
+def _pedersen_commit_batch(self, v, blind):
+    """PedersenGens::commit for m (value, blinding) pairs (ark words, m x 4 each) -> m x 8 affine words"""
+    v, blind = u64arr(v, 4), u64arr(blind, 4)
+    if v.shape != blind.shape:
+        raise ValueError("pedersen_commit_batch: length mismatch")
+    out = np.zeros((v.shape[0], 8), dtype=np.uint64)
+    check(lib().bp_pedersen_commit_batch(self.ctx, ptr(v), ptr(blind), C.c_size_t(v.shape[0]), ptr(out)), "bp_pedersen_commit_batch")
+    return out
+
+
 def _share_gens_from(self, other):
     check(lib().bp_gens_share(self.ctx, other.ctx), "bp_gens_share")
     self.gens_capacity = getattr(other, "gens_capacity", 0)
@@ -359,6 +375,7 @@ def _share_gens_from(self, other):
 
 
 Engine.share_gens_from = _share_gens_from
+Engine.pedersen_commit_batch = _pedersen_commit_batch
 
 
 def precompute_batch(stmts):

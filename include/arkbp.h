@@ -133,6 +133,11 @@ int bp_host_points_sum(int curve, const uint64_t* pts_xy, size_t count, uint64_t
 int bp_r1cs_prove_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, const uint8_t seed[32], uint8_t* proof_out, size_t* proof_len,
                            uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, double* timing);
 
+/* `PedersenGens::commit` (src/generators.rs:39-44) for m (value, blinding) pairs at once: out[i] = v[i]*B + blind[i]*B_blinding
+ * with PedersenGens::default()'s bases, by fixed-base window tables on the GPU.  v, blind: m x 4 words (ark layout);
+ * out_xy: m x 8 words (affine, ark layout; the identity is all-zero). */
+int bp_pedersen_commit_batch(bp_ctx* ctx, const uint64_t* v, const uint64_t* blind, size_t m, uint64_t* out_xy);
+
 /* Statement handles: `Prover::new` + `commit`s + gadget (src/r1cs/prover.rs:291-341; host only, no GPU) separated from
  * `prove()` so that a service can keep several proofs in flight: the per-proof TranscriptRng chain (8 Keccak-f per
  * multiplier, strictly sequential inside one proof) of one statement overlaps the GPU work of the others.  Each in-flight
@@ -140,6 +145,9 @@ int bp_r1cs_prove_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, co
  * bp_stmt_prove consumes the statement (`prove(self, ..)`); timing as in bp_r1cs_prove_scenario ([1] = 0). */
 typedef struct bp_stmt bp_stmt;
 int bp_stmt_prover_create(int curve, int scenario, const uint64_t* params, const uint8_t seed[32], bp_stmt** out);
+/* same, with the statement's Pedersen commitments (`Prover::commit`, src/r1cs/prover.rs:327-341) computed on ctx's GPU in one
+ * batch; the curve is ctx's.  Identical statement (same transcript, same commitments) as the host-only constructor. */
+int bp_stmt_prover_create_dev(bp_ctx* ctx, int scenario, const uint64_t* params, const uint8_t seed[32], bp_stmt** out);
 void bp_stmt_free(bp_stmt* stmt);
 int bp_stmt_info(bp_stmt* stmt, uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, size_t* multipliers,
                  size_t* constraints);
