@@ -63,12 +63,14 @@ struct bp_ctx {
     int curve = 0, device = 0;
     hipStream_t stream = nullptr;
     bool profiling = false;
+    size_t tune_fold_batch_min = 65536;   // BP_TUNE_FOLD_BATCH_MIN
+    size_t tune_msm_bin_min = 4096;       // BP_TUNE_MSM_BIN_MIN
     KTimer timers[BP_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // MSM workspaces
     DevBuf canon, hist, lvl_off, totals, cursor, entries, slots, bin_cur, boff, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
     // IPA workspaces (resident layouts)
-    DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q;
+    DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q, ipa_jac, ipa_pref;
     // generator tables (BulletproofGens party 0, PedersenGens), resident layout
     DevBuf d_G, d_H, d_pc;
     DevBuf pc_table;   // fixed-base window tables of B, B_blinding (pedersen.cuh), built on first use
@@ -163,7 +165,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         const int bits_last = C::Fr::BITS - pl.c * (pl.W - 1);
         const int wbn = bits_last < pl.c - 1 ? pl.W - 1 : pl.W;
         static const bool no_bins = getenv("ARKBP_MSM_NOBIN") != nullptr;
-        if (n >= 4096 && wbn > 0 && !no_bins) {
+        if (n >= ctx->tune_msm_bin_min && wbn > 0 && !no_bins) {
             u32 nbin = 1, lg = 0;
             while ((size_t)nbin * 8192 < n && nbin < (u32)pl.NB) { nbin <<= 1; lg++; }
             int LB = pl.c - 1 - (int)lg;
@@ -405,19 +407,45 @@ template <class C> static bool glv_decompose(const F4& t, u32 p1[5], u32 m1[5], 
 template <class C> static bool glv_pair(const F4& tG, const F4& tH, Naf2& g, Naf2& h) {
     return glv_decompose<C>(tG, g.p1, g.m1, g.p2, g.m2) && glv_decompose<C>(tH, h.p1, h.m1, h.p2, h.m2);
 }
+// Rounds with at least 2^16 output points convert to affine through k_ipa_fold_finish (one inversion per m points); smaller
+// rounds are launch/latency bound and keep the in-lane inversion.
+struct FoldFinish { u32* jac = nullptr; u32* pref = nullptr; u32 m = 0; };
+static int fold_finish_plan(bp_ctx* ctx, size_t lanes, FoldFinish& ff) {
+    static const bool off = getenv("ARKBP_FOLD_NOBATCH") != nullptr;
+    ff = FoldFinish();
+    if (off || lanes < ctx->tune_fold_batch_min) return BP_OK;
+    BPCHK(ctx->ipa_jac.ensure(lanes * 96));
+    BPCHK(ctx->ipa_pref.ensure(lanes * 32));
+    ff.jac = ctx->ipa_jac.as<u32>(); ff.pref = ctx->ipa_pref.as<u32>();
+    ff.m = (u32)std::min<size_t>(8, std::max<size_t>(2, lanes / 32768));   // keep >= 2^15 lanes busy
+    return BP_OK;
+}
+template <class C> static void fold_finish_launch(hipStream_t st, const FoldFinish& ff, u32* d_G, u32* d_H, size_t n, int which, size_t lanes) {
+    if (!ff.jac) return;
+    const u32 threads = (u32)((lanes + ff.m - 1) / ff.m);
+    hipLaunchKernelGGL(k_ipa_fold_finish<C>, dim3((threads + 255) / 256), dim3(256), 0, st, ff.jac, ff.pref, d_G, d_H, (u32)n, which, (u32)lanes, ff.m);
+}
 // launches the uniform fold for multipliers (tG, tH): GLV ladder where the curve has the endomorphism, plain NAF ladder otherwise
-template <class C> static void launch_uniform_fold(hipStream_t st, u32* d_G, u32* d_H, size_t n, const F4& tG, const F4& tH, int which) {
+template <class C> static int launch_uniform_fold(bp_ctx* ctx, u32* d_G, u32* d_H, size_t n, const F4& tG, const F4& tH, int which) {
     typedef host::Fld<typename C::Fr> S;
+    hipStream_t st = ctx->stream;
     const u32 lanes = (u32)(which == 3 ? 2 * n : n);
+    FoldFinish ff;
+    BPCHK(fold_finish_plan(ctx, lanes, ff));
+    bool done = false;
     if constexpr (C::HAS_GLV) {
         Naf2 g, h;
         if (glv_pair<C>(tG, tH, g, h)) {
-            hipLaunchKernelGGL(k_ipa_fold_glv<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, g, h, which);
-            return;
+            hipLaunchKernelGGL(k_ipa_fold_glv<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, g, h, which, ff.jac);
+            done = true;
         }
     }
-    Naf a = naf_of<S>(tG), b = naf_of<S>(tH);
-    hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, a, b, which);
+    if (!done) {
+        Naf a = naf_of<S>(tG), b = naf_of<S>(tH);
+        hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, a, b, which, ff.jac);
+    }
+    fold_finish_launch<C>(st, ff, d_G, d_H, n, which, lanes);
+    return BP_OK;
 }
 
 template <class C>
@@ -476,8 +504,8 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                 const int k = lg2(n);
                 const F4 s2 = S::mul(u, gf_halves[1]);
                 const F4 ginv = S::inv(gf_halves[1]);
-                launch_uniform_fold<C>(st, d_G, d_H, n, S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)),
-                                       S::mul(S::mul(S::sqr(u), S::mul(gf_halves[0], ginv)), rho_pw[k]), 3);
+                BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)),
+                                             S::mul(S::mul(S::sqr(u), S::mul(gf_halves[0], ginv)), rho_pw[k]), 3));
                 gamma_G = S::mul(gamma_G, s2);
                 gamma_H = S::mul(S::mul(ui, gf_halves[1]), rho_pw[32 + k]);
                 pending = true; h_geo = true;
@@ -485,18 +513,24 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                 // G: u^-1*gL*G_L + u*gR*G_R = (u*gR) * (G_R + t*G_L), t = u^-1*gL / (u*gR): uniform, one NAF ladder; H: per-lane factors
                 const F4 s2 = S::mul(u, gf_halves[1]);
                 const F4 tG = S::mul(S::mul(ui, gf_halves[0]), S::inv(s2));
-                launch_uniform_fold<C>(st, d_G, d_H, n, tG, tG, 1);
-                hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u), words_of<S>(ui), 2);
+                BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, tG, tG, 1));
+                FoldFinish ff;
+                BPCHK(fold_finish_plan(ctx, n, ff));
+                hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u), words_of<S>(ui), 2, ff.jac);
+                fold_finish_launch<C>(st, ff, d_G, d_H, n, 2, n);
                 gamma_G = S::mul(gamma_G, s2);
                 pending = true;
             } else if (first) {
+                FoldFinish ff;
+                BPCHK(fold_finish_plan(ctx, 2 * n, ff));
                 hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u),
-                                   words_of<S>(ui), 3);
+                                   words_of<S>(ui), 3, ff.jac);
+                fold_finish_launch<C>(st, ff, d_G, d_H, n, 3, 2 * n);
             } else {
                 // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
                 // (geometric pending factor: c[i]/c[n+i] = rho^-n joins t, and K picks up rho^n)
                 const int k = lg2(n);
-                launch_uniform_fold<C>(st, d_G, d_H, n, S::sqr(ui), h_geo ? S::mul(S::sqr(u), rho_pw[k]) : S::sqr(u), 3);
+                BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, S::sqr(ui), h_geo ? S::mul(S::sqr(u), rho_pw[k]) : S::sqr(u), 3));
                 gamma_G = S::mul(gamma_G, u);
                 gamma_H = h_geo ? S::mul(S::mul(gamma_H, ui), rho_pw[32 + k]) : S::mul(gamma_H, ui);
                 pending = true;
@@ -678,7 +712,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     collect_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
-                      &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q,
+                      &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
                       &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart};
     c->templates.clear();
@@ -687,6 +721,14 @@ void bp_ctx_destroy(bp_ctx* c) {
     if (c->h_T) (void)hipHostFree(c->h_T);
     (void)hipStreamDestroy(c->stream);
     delete c;
+}
+int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
+    if (!c) return BP_E_ARG;
+    switch (knob) {
+        case BP_TUNE_FOLD_BATCH_MIN: c->tune_fold_batch_min = (size_t)value; return BP_OK;
+        case BP_TUNE_MSM_BIN_MIN: c->tune_msm_bin_min = (size_t)value; return BP_OK;
+    }
+    return BP_E_ARG;
 }
 int bp_ctx_sync(bp_ctx* c) {
     if (!c) return BP_E_ARG;

@@ -195,11 +195,62 @@ template <class C> __device__ __forceinline__ Jac shamir2(const Aff& P1, const A
     return acc;
 }
 
+// Fold epilogue.  jac_ws == nullptr: the lane inverts its own Z (one a^(p-2) ladder, ~450 products) and writes the affine point.
+// Large rounds pass a workspace instead: lane t leaves its Jacobian result there and k_ipa_fold_finish converts the whole
+// round with ONE inversion per m points (Montgomery's trick along a strided run of points per lane).
+template <class C> __device__ __forceinline__ void fold_emit(u32* __restrict__ V, u32 i, u32 t, const Jac& acc, u32* __restrict__ jac_ws) {
+    if (jac_ws) { store_jac_ws<C>(jac_ws + (size_t)t * 24, acc); return; }
+    const Aff o = jac_to_aff<C>(acc);
+    u32 w[16];
+    aff_store_dev(w, o);
+    store_words8(V + (size_t)i * 16, w);
+    store_words8(V + (size_t)i * 16 + 8, w + 8);
+}
+// lane t0 owns the points t0, t0 + T, t0 + 2T, ... (T = all lanes of the grid; coalesced at every step)
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_fold_finish(const u32* __restrict__ jac_ws, u32* __restrict__ pref_ws, u32* __restrict__ G, u32* __restrict__ H, u32 n, int which, u32 total, u32 m) {
+    typedef typename C::Fq F;
+    const u32 T = gridDim.x * blockDim.x;
+    const u32 t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 >= total) return;
+    Fe acc = fe_one<F>();
+    u32 cnt = 0;
+    for (u32 p = t0; cnt < m && p < total; cnt++, p += T) {
+        u32 w[8];
+        load_words8(w, jac_ws + (size_t)p * 24 + 16);
+        const Fe z = fe_unpack(w);
+        if (!fe_is_zero_exact(z)) acc = fe_mul<F>(acc, z);
+        fe_pack(w, fe_canon<F>(acc));
+        store_words8(pref_ws + (size_t)p * 8, w);
+    }
+    Fe inv = fe_inv<F>(acc);
+    for (int j = (int)cnt - 1; j >= 0; j--) {
+        const u32 p = t0 + (u32)j * T;
+        const Jac P = load_jac_ws(jac_ws + (size_t)p * 24);
+        Aff o;
+        if (jac_is_inf(P)) { o.x = fe_zero<F>(); o.y = fe_zero<F>(); }
+        else {
+            Fe prev = fe_one<F>();
+            if (j > 0) { u32 w[8]; load_words8(w, pref_ws + (size_t)(p - T) * 8); prev = fe_unpack(w); }
+            const Fe zinv = fe_mul<F>(inv, prev);
+            inv = fe_mul<F>(inv, P.Z);
+            o = jac_to_aff_with_zinv<C>(P, zinv);
+        }
+        const bool isH = which == 2 || (which == 3 && p >= n);
+        const u32 i = (which == 3 && isH) ? p - n : p;
+        u32* V = isH ? H : G;
+        u32 w[16];
+        aff_store_dev(w, o);
+        store_words8(V + (size_t)i * 16, w);
+        store_words8(V + (size_t)i * 16 + 8, w + 8);
+    }
+}
+
 // One lane per output point: lanes [0,n) fold G, lanes [n,2n) fold H.  first != 0: per-element factors.
 // u, u_inv ark Montgomery words.  In place: lane i reads elements i and n+i of its vector, writes i.
 template <class C> __global__ void __launch_bounds__(256)
 k_ipa_fold_pts(u32* __restrict__ G, u32* __restrict__ H, const u32* __restrict__ Gf, const u32* __restrict__ Hf, int first, u32 n, Words8 uw,
-               Words8 uiw, int which /* 1: G only, 2: H only, 3: both */) {
+               Words8 uiw, int which /* 1: G only, 2: H only, 3: both */, u32* __restrict__ jac_ws) {
     typedef typename C::Fr F;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (which == 3 ? 2 * n : n)) return;
@@ -218,11 +269,7 @@ k_ipa_fold_pts(u32* __restrict__ G, u32* __restrict__ H, const u32* __restrict__
     fe_store_canon<F>(s2, c2);
     const Aff P1 = load_aff_dev(V + (size_t)i * 16), P2 = load_aff_dev(V + (size_t)(n + i) * 16);
     const Jac r = shamir2<C>(P1, P2, s1, s2);
-    const Aff o = jac_to_aff<C>(r);
-    u32 w[16];
-    aff_store_dev(w, o);
-    store_words8(V + (size_t)i * 16, w);
-    store_words8(V + (size_t)i * 16 + 8, w + 8);
+    fold_emit<C>(V, i, t, r, jac_ws);
 }
 
 // Uniform-scalar rounds (every round after the first; src/inner_product_proof.rs:219-224).  With the same (u^-1, u) for all
@@ -234,7 +281,8 @@ struct Naf {
     u32 plus[9], minus[9];
 };
 template <class C> __global__ void __launch_bounds__(256)
-k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf tH, int which /* 1: G only, 2: H only, 3: both */) {
+k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf tH, int which /* 1: G only, 2: H only, 3: both */,
+                   u32* __restrict__ jac_ws) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (which == 3 ? 2 * n : n)) return;
     const bool isH = which == 2 || (which == 3 && t >= n);  // waves are homogeneous for n >= 64
@@ -254,11 +302,7 @@ k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf 
         }
     }
     acc = jac_madd<C>(acc, P2);
-    const Aff o = jac_to_aff<C>(acc);
-    u32 w[16];
-    aff_store_dev(w, o);
-    store_words8(V + (size_t)i * 16, w);
-    store_words8(V + (size_t)i * 16 + 8, w + 8);
+    fold_emit<C>(V, i, t, acc, jac_ws);
 }
 
 // GLV variant of the uniform fold for curves with the j = 0 endomorphism phi(x, y) = (beta*x, y) = [lambda](x, y) (secq256k1):
@@ -268,7 +312,8 @@ struct Naf2 {
     u32 p1[5], m1[5], p2[5], m2[5];   // bit i: digit +1 / -1 at 2^i of t1 (p1/m1) and t2 (p2/m2), 130 digits
 };
 template <class C> __global__ void __launch_bounds__(256)
-k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH, int which /* 1: G only, 2: H only, 3: both */) {
+k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH, int which /* 1: G only, 2: H only, 3: both */,
+               u32* __restrict__ jac_ws) {
     typedef typename C::Fq F;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (which == 3 ? 2 * n : n)) return;
@@ -279,7 +324,7 @@ k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH
     Aff Q1;   // phi(P1); the identity (0,0) maps to itself
     Q1.x = fe_canon<F>(fe_mul<F>(P1.x, fe_const<F, C::BETA29>()));
     Q1.y = P1.y;
-    const Aff N1 = aff_cneg_lazy<C>(P1, true), NQ1 = aff_cneg_lazy<C>(Q1, true);
+    const Aff N1 = aff_cneg_lazy<C>(P1, true);   // phi keeps y: -phi(P1) = (beta*x, -y)
     Jac acc = jac_inf<C>();
 #pragma unroll 1
     for (int wd = 4; wd >= 0; wd--) {
@@ -288,18 +333,12 @@ k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH
 #pragma unroll 1
         for (int bit = (wd == 4 ? 1 : 31); bit >= 0; bit--) {
             acc = jac_dbl<C>(acc);
-            if ((a >> bit) & 1) acc = jac_madd<C>(acc, P1);
-            else if ((b >> bit) & 1) acc = jac_madd<C>(acc, N1);
-            if ((c >> bit) & 1) acc = jac_madd<C>(acc, Q1);
-            else if ((d >> bit) & 1) acc = jac_madd<C>(acc, NQ1);
+            if (((a | b) >> bit) & 1) { Aff T1 = P1; T1.y = ((b >> bit) & 1) ? N1.y : P1.y; acc = jac_madd<C>(acc, T1); }   // masks are wave-uniform
+            if (((c | d) >> bit) & 1) { Aff T2 = Q1; T2.y = ((d >> bit) & 1) ? N1.y : P1.y; acc = jac_madd<C>(acc, T2); }
         }
     }
     acc = jac_madd<C>(acc, P2);
-    const Aff o = jac_to_aff<C>(acc);
-    u32 w[16];
-    aff_store_dev(w, o);
-    store_words8(V + (size_t)i * 16, w);
-    store_words8(V + (size_t)i * 16 + 8, w + 8);
+    fold_emit<C>(V, i, t, acc, jac_ws);
 }
 
 }  // namespace arkbp

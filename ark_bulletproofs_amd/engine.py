@@ -85,6 +85,10 @@ class Engine:
         check(lib().bp_msm_dev(self.ctx, d_bases.ptr, d_scalars.ptr, C.c_size_t(n), int(canonical), ptr(out)), "bp_msm_dev")
         return out
 
+    def set_tuning(self, knob, value):
+        """knob: 0 fold-batch minimum lanes, 1 MSM two-level-sort minimum terms (include/arkbp.h BP_TUNE_*)"""
+        check(lib().bp_ctx_set_tuning(self.ctx, int(knob), C.c_uint64(int(value))), "bp_ctx_set_tuning")
+
     # ---- profiling ------------------------------------------------------------------------------
     def set_profiling(self, on=True):
         check(lib().bp_ctx_set_profiling(self.ctx, int(on)), "bp_ctx_set_profiling")

@@ -191,6 +191,13 @@ int bp_ctx_set_profiling(bp_ctx* ctx, int enabled);
 int bp_ctx_kernel_time(bp_ctx* ctx, int which, double* ms_total, uint64_t* launches);
 int bp_ctx_reset_profiling(bp_ctx* ctx);
 
+/* Size thresholds at which the engine switches kernels (results never depend on them; the tests lower them to drive the
+ * large-input paths with small inputs).  FOLD_BATCH_MIN: output points per IPA fold round from which the affine conversion
+ * shares inversions (default 65536); MSM_BIN_MIN: terms from which the MSM uses the two-level sort (default 4096). */
+#define BP_TUNE_FOLD_BATCH_MIN 0
+#define BP_TUNE_MSM_BIN_MIN 1
+int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
+
 /* ---- unit-test hooks: one field / group operation per element on the GPU -------------------------- */
 /* field: 2*curve + (0 base field | 1 scalar field); op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inv */
 int bp_debug_field_op(bp_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

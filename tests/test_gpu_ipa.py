@@ -117,3 +117,27 @@ def test_ipa_verify_on_gpu(eng, oracle, n):
 
     Lg, Rg, ag, bg = eng.ipa_create(Q, Gf, Hf, G, H, a, b, chal)
     assert eng.ipa_verify(n, Gf, Hf, P, Q, G, H, Lg, Rg, np.array(chg).reshape(-1, 4), ag, bg) == 0
+
+
+@pytest.mark.parametrize("n", [4, 64, 256])
+def test_ipa_create_large_round_kernels_at_small_sizes(oracle, n):
+    """the kernels large rounds switch to (shared-inversion fold epilogue k_ipa_fold_finish, two-level MSM sort) driven with
+    small inputs through bp_ctx_set_tuning: same bytes as the oracle"""
+    import ark_bulletproofs_amd as A
+
+    O = oracle
+    for cv in (0, 1):
+        e = A.Engine(curve=cv)
+        e.set_tuning(0, 1)
+        e.set_tuning(1, 1)
+        G, H, Q, a, b, Gf, Hf, P = _ipa_instance(O, cv, n)
+        H = H.copy()
+        H[0] = 0                      # an identity among the folded points (Z = 0 inside the shared inversion)
+        tr = O.Transcript(b"innerproducttest")
+        tr_ref = tr.clone()
+        Lo, Ro, ao, bo = O.ipa_create(cv, tr_ref, Q, Gf, Hf, G, H, a, b)
+        tr.append_message(b"dom-sep", b"ipp v1")
+        tr.append_u64(b"n", n)
+        Lg, Rg, ag, bg = e.ipa_create(Q, Gf, Hf, G, H, a, b, _challenger(O, cv, tr))
+        assert (Lg == Lo).all() and (Rg == Ro).all() and (ag == ao).all() and (bg == bo).all()
+        e.close()

@@ -119,6 +119,20 @@ def test_msm_edge_cases(eng, oracle):
         eng.msm(G[:4], sc[:3])
 
 
+def test_msm_two_level_sort_forced_small(eng, oracle):
+    """two-level sort with a handful of terms (bins of a few entries, empty bins, the narrow top window in LDS)"""
+    O, cv = oracle, eng.curve
+    eng.set_tuning(1, 1)
+    try:
+        for n in (1, 2, 31, 33, 257, 1000):
+            G, H = O.bp_gens(cv, max(n, 2))
+            bases = np.concatenate([G, H])[:n]
+            sc = _rand_scalars(O, cv, n, (40 + n) % 200)
+            assert (eng.msm(bases, sc) == O.msm(cv, bases, sc)).all()
+    finally:
+        eng.set_tuning(1, 4096)
+
+
 def test_msm_two_level_sort_sizes(eng, oracle):
     """sizes that take the two-level (binned) sort: uniform scalars, skew that overflows a bin region (falls back to the slot /
     exact paths), 0/1 and r-1 vectors, zero scalars and identity bases in between, canonical input"""
