@@ -64,7 +64,7 @@ struct bp_ctx {
     hipStream_t stream = nullptr;
     bool profiling = false;
     size_t tune_fold_batch_min = 65536;   // BP_TUNE_FOLD_BATCH_MIN
-    size_t tune_msm_bin_min = 4096;       // BP_TUNE_MSM_BIN_MIN
+    size_t tune_msm_bin_min = 64;         // BP_TUNE_MSM_BIN_MIN
     KTimer timers[BP_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // MSM workspaces

@@ -130,7 +130,7 @@ def test_msm_two_level_sort_forced_small(eng, oracle):
             sc = _rand_scalars(O, cv, n, (40 + n) % 200)
             assert (eng.msm(bases, sc) == O.msm(cv, bases, sc)).all()
     finally:
-        eng.set_tuning(1, 4096)
+        eng.set_tuning(1, 64)
 
 
 def test_msm_two_level_sort_sizes(eng, oracle):
