@@ -79,7 +79,10 @@ struct bp_ctx {
     // R1CS prover / verifier vectors (resident scalar layout)
     DevBuf r_aL, r_aR, r_aO, r_sL, r_sR, r_wL, r_wR, r_wO, r_msmsc, r_ypow, r_part, r_small, r_g, r_h, r_chal, r_tail;
     // batch verification: per-proof parameter blocks, chunk partials; cached circuit templates (VTemplate<C>)
-    DevBuf v_params, v_gpart, v_hpart;
+    DevBuf v_params, v_gpart, v_hpart, v_alpha;
+    void* h_vstage[2] = {nullptr, nullptr};   // pinned staging halves of the batch-verify pipeline
+    size_t h_vstage_cap[2] = {0, 0};
+    hipEvent_t vstage_ev[2] = {nullptr, nullptr};
     std::map<std::string, std::shared_ptr<void>> templates;
     u32* h_totals = nullptr;  // pinned
     u32* h_T = nullptr;       // pinned
@@ -140,7 +143,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (pl.w_lo >= pl.w_hi) return BP_OK;  // this rank owns no window: the identity
     constexpr int NL = MSM_NLMAX;
     int nl = 2;  // levels 0..nl-1 can be needed: 16^(nl-1) >= n
-    { u64 cap = MSM_CH; while (cap < n && nl < NL) { cap *= MSM_CH; nl++; } }
+    { u64 cap = MSM_CH; while (cap < n && nl < NL) { cap *= MSM_CH; nl++; } }   // sized for the smaller fan-in
     const size_t Bp1 = (size_t)pl.B + 1;
     const u32 ntiles = (pl.B + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
     BPCHK(ctx->canon.ensure(n * 32));
@@ -207,7 +210,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     const int TB = 256;
     const u32 gb = (u32)((n + TB - 1) / TB);
     // front end: digits, histogram, placement, scans; leaves the totals (and the overflow flag) in h_totals
+    int chl = MSM_CHL;
     auto front_end = [&](bool bins) -> int {
+        chl = bins ? MSM_CHL_BINNED : MSM_CHL;
         const size_t nslots = make_slots(sp, bins ? (int)bp.wb : 0, bins ? (size_t)bp.wb * bp.NBIN * bp.cap : 0);
         if (nslots >= ((size_t)1 << 32)) { g_err = "msm: slot array too large"; return BP_E_ARG; }
         BPCHK(ctx->slots.ensure(nslots * 4));
@@ -230,9 +235,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
             hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont, sp,
                                ctx->slots.as<u32>(), d_over);
         }
-        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl);
+        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl, chl);
         hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
-        hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl);
+        hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl, chl);
         HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
@@ -256,19 +261,19 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (tot[0] == 0) { total.stop(); return BP_OK; }  // every digit zero: the identity
     // levels: 1 = chunks of entries; k >= 2 = chunks of level k-1 partials; stop when a bucket holds <= 1
     int K = 1;
-    { u64 cap = MSM_CH; while (cap < maxcnt) { cap *= MSM_CH; K++; } }
+    { u64 cap = (u64)1 << chl; while (cap < maxcnt) { cap <<= chl; K++; } }
     if (K >= nl) { g_err = "msm: bucket population exceeds the reduction depth"; return BP_E_ARG; }
     BPCHK(ctx->lvA.ensure((size_t)tot[1] * 96));
     if (K >= 2) BPCHK(ctx->lvB.ensure((size_t)tot[2] * 96));
     {
         ScopedK acc(ctx, BP_K_MSM_ACCUM);
         hipLaunchKernelGGL(k_msm_accum<C>, dim3((tot[1] + TB - 1) / TB), dim3(TB), 0, st, segs, entries_ptr, lvl, lvl + Bp1, ctx->lvA.as<u32>(), pl.B,
-                           tot[1], slotted ? (binned ? 2 : 1) : 0, sp, (u32)pl.NB, ctx->boff.as<u32>());
+                           tot[1], slotted ? (binned ? 2 : 1) : 0, sp, (u32)pl.NB, ctx->boff.as<u32>(), chl);
     }
     u32* cur = ctx->lvA.as<u32>();
     u32* nxt = ctx->lvB.as<u32>();
     for (int k = 2; k <= K; k++) {
-        hipLaunchKernelGGL(k_msm_reduce<C>, dim3((tot[k] + TB - 1) / TB), dim3(TB), 0, st, cur, lvl + Bp1 * (k - 1), lvl + Bp1 * k, nxt, pl.B, tot[k]);
+        hipLaunchKernelGGL(k_msm_reduce<C>, dim3((tot[k] + TB - 1) / TB), dim3(TB), 0, st, cur, lvl + Bp1 * (k - 1), lvl + Bp1 * k, nxt, pl.B, tot[k], chl);
         u32* t = cur; cur = nxt; nxt = t;
     }
     hipLaunchKernelGGL(k_msm_marginals<C>, dim3(pl.W, pl.c), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl);
@@ -714,11 +719,12 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
-                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart};
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha};
     c->templates.clear();
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
+    for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -26,7 +26,10 @@ namespace arkbp {
 #ifndef ARKBP_MSM_CH
 #define ARKBP_MSM_CH 16
 #endif
-static constexpr int MSM_CH = ARKBP_MSM_CH;  // entries per level-1 lane / fan-in of the reduction tree
+static constexpr int MSM_CH = ARKBP_MSM_CH;  // entries per level-1 lane / fan-in of the reduction tree on the skew-tolerant path
+static constexpr int MSM_CHL = MSM_CH == 8 ? 3 : MSM_CH == 16 ? 4 : MSM_CH == 32 ? 5 : 6;
+static_assert((1 << MSM_CHL) == MSM_CH, "ARKBP_MSM_CH must be 8, 16, 32 or 64");
+static constexpr int MSM_CHL_BINNED = MSM_CHL;   // measured: whole-bucket lanes (64) lose more to divergence and a thin grid than the tree levels cost
 static constexpr int MSM_MAXLVL = 8;   // 16^8 = 2^32 >= any bucket population
 static constexpr int MSM_MAXSEG = 4;
 
@@ -309,7 +312,7 @@ k_msm_bin_sort(u32* __restrict__ ent, const u32* __restrict__ bin_cur, u32* __re
 static constexpr int MSM_NLMAX = MSM_MAXLVL + 1;
 static constexpr int MSM_SCAN_TILE = 2048;  // buckets per workgroup (256 lanes x 8)
 
-__global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ hist, u32* __restrict__ tile_sums, u32 B, int nl) {
+__global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ hist, u32* __restrict__ tile_sums, u32 B, int nl, int chl) {
     __shared__ u32 sh[MSM_NLMAX + 1][4];
     const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
     u32 sum[MSM_NLMAX + 1];
@@ -318,7 +321,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ 
         const u32 b = base + j;
         u32 v = b < B ? hist[b] : 0;
         sum[MSM_NLMAX] = max(sum[MSM_NLMAX], v);
-        for (int k = 0; k < nl; k++) { sum[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
+        for (int k = 0; k < nl; k++) { sum[k] += v; v = (v + (1u << chl) - 1) >> chl; }
     }
     for (int k = 0; k <= MSM_NLMAX; k++) {
         u32 v = sum[k];
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(64) k_msm_scan_top(u32* __restrict__ tile_sums
     totals[k] = run;
     if (k < MSM_NLMAX) lvl_off[(size_t)k * (B + 1) + B] = run;
 }
-__global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl) {
+__global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl, int chl) {
     __shared__ u32 sh[MSM_NLMAX][4];
     const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ 
         const u32 b = base + j;
         u32 v = b < B ? hist[b] : 0;
         cnt[j] = v;
-        for (int k = 0; k < nl; k++) { sum[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
+        for (int k = 0; k < nl; k++) { sum[k] += v; v = (v + (1u << chl) - 1) >> chl; }
     }
     u32 excl[MSM_NLMAX];
     for (int k = 0; k < nl; k++) {   // inclusive scan across the wave, then exclusive
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ 
         const u32 b = base + j;
         if (b >= B) break;
         u32 v = cnt[j];
-        for (int k = 0; k < nl; k++) { lvl_off[(size_t)k * (B + 1) + b] = excl[k]; excl[k] += v; v = (v + MSM_CH - 1) / MSM_CH; }
+        for (int k = 0; k < nl; k++) { lvl_off[(size_t)k * (B + 1) + b] = excl[k]; excl[k] += v; v = (v + (1u << chl) - 1) >> chl; }
     }
 }
 
@@ -409,22 +412,22 @@ __device__ __forceinline__ u32 find_bucket(const u32* __restrict__ off, u32 B, u
 // 4. level 1: lane j sums the j-th CH-entry chunk (mixed adds of gathered affine bases)
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restrict__ off0, const u32* __restrict__ off1, u32* __restrict__ out,
-            u32 B, u32 nchunks, int slotted, SlotPlan sp, u32 NB, const u32* __restrict__ boff) {
+            u32 B, u32 nchunks, int slotted, SlotPlan sp, u32 NB, const u32* __restrict__ boff, int chl) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nchunks) return;
     const u32 b = find_bucket(off1, B, j);
     u32 beg, end;
     if (slotted == 2) {  // two-level sort: bucket b starts at boff[b]; its population is off0[b+1] - off0[b]
-        beg = boff[b] + (j - off1[b]) * MSM_CH;
-        end = min(beg + MSM_CH, boff[b] + (off0[b + 1] - off0[b]));
+        beg = boff[b] + ((j - off1[b]) << chl);
+        end = min(beg + (1u << chl), boff[b] + (off0[b + 1] - off0[b]));
     } else if (slotted) {  // entries = slot array; the bucket's population is off0[b+1] - off0[b]
         const u32 w = b / NB, v = b - w * NB;
         const u32 s0 = sp.base[w] + v * sp.cap[w];
-        beg = s0 + (j - off1[b]) * MSM_CH;
-        end = min(beg + MSM_CH, s0 + (off0[b + 1] - off0[b]));
+        beg = s0 + ((j - off1[b]) << chl);
+        end = min(beg + (1u << chl), s0 + (off0[b + 1] - off0[b]));
     } else {
-        beg = off0[b] + (j - off1[b]) * MSM_CH;
-        end = min(beg + MSM_CH, off0[b + 1]);
+        beg = off0[b] + ((j - off1[b]) << chl);
+        end = min(beg + (1u << chl), off0[b + 1]);
     }
     Jac acc = jac_inf<C>();
     for (u32 e = beg; e < end; e++) {
@@ -438,12 +441,12 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
 // 5. level k >= 2: lane j sums chunk j of level k-1 partials
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_reduce(const u32* __restrict__ in, const u32* __restrict__ off_prev, const u32* __restrict__ off_cur, u32* __restrict__ out, u32 B,
-             u32 nchunks) {
+             u32 nchunks, int chl) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nchunks) return;
     const u32 b = find_bucket(off_cur, B, j);
-    const u32 beg = off_prev[b] + (j - off_cur[b]) * MSM_CH;
-    const u32 end = min(beg + MSM_CH, off_prev[b + 1]);
+    const u32 beg = off_prev[b] + ((j - off_cur[b]) << chl);
+    const u32 end = min(beg + (1u << chl), off_prev[b + 1]);
     Jac acc = load_jac_ws(in + (size_t)beg * 24);
     for (u32 e = beg + 1; e < end; e++) acc = jac_add<C>(acc, load_jac_ws(in + (size_t)e * 24));
     store_jac_ws<C>(out + (size_t)j * 24, acc);

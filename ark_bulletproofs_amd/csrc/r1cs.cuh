@@ -276,6 +276,21 @@ k_ipa_vfy_scalars(const u32* __restrict__ Gf, const u32* __restrict__ Hf, const 
     store_fe_canon<F>(h_out + o, fe_mul<F>(fe_mul<F>(b, s_rev), load_fe_dev<F>(Hf + o)));
 }
 
+// tail scalars of the batched mega-check (verifier.rs:652-683): s <- canonical(alpha_p * s) for every tail scalar of proof p.
+// tails: ark words in, canonical integers out; alphas: resident form; toff: P+1 prefix offsets of the per-proof tail ranges.
+template <class F> __global__ void __launch_bounds__(256)
+k_vfy_tail_scale(u32* __restrict__ tails, const u32* __restrict__ alphas, const u32* __restrict__ toff, u32 P, u32 T) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    u32 lo = 0, hi = P;   // toff[lo] <= j < toff[hi]
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (toff[mid] <= j) lo = mid; else hi = mid; }
+    u32 w[8];
+    load_words8(w, tails + (size_t)j * 8);
+    const Fe s = fe_load_ark<F>(w), a = load_fe_dev<F>(alphas + (size_t)lo * 8);
+    fe_store_canon<F>(w, fe_mul<F>(s, a));
+    store_words8(tails + (size_t)j * 8, w);
+}
+
 // resident form -> canonical integers, in place
 template <class F> __global__ void k_scalars_to_canon(u32* __restrict__ v, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;

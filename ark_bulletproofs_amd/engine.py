@@ -284,23 +284,37 @@ def _verify_scenario(self, scenario, params, proof, commitments, publics):
                                          ptr(pb), C.c_size_t(len(pb)))
 
 
+class PackedInstances:
+    """The flat arrays bp_r1cs_batch_verify_scenarios takes (what a caller in the reference's language would hand over directly),
+    built once from a list of (scenario, params, proof_bytes, commitments, publics)."""
+
+    def __init__(self, instances):
+        n = len(instances)
+        self.n = n
+        self.scen = (C.c_int * n)(*[i[0] for i in instances])
+        self.prm = np.concatenate([_prm(i[1]) for i in instances])
+        self.proofs = b"".join(i[2] for i in instances)
+        self.plens = (C.c_size_t * n)(*[len(i[2]) for i in instances])
+        cm_l = [np.asarray(i[3], dtype=np.uint64).reshape(-1, 8) for i in instances]
+        self.cms = np.ascontiguousarray(np.concatenate(cm_l))
+        self.ms = (C.c_size_t * n)(*[len(c) for c in cm_l])
+        pubs_l = [np.asarray(i[4], dtype=np.uint64).reshape(-1, 4) for i in instances]
+        self.pubs = np.ascontiguousarray(np.concatenate(pubs_l + [np.zeros((1, 4), dtype=np.uint64)]))
+        self.npubs = (C.c_size_t * n)(*[len(p) for p in pubs_l])
+
+
+def pack_instances(instances):
+    return PackedInstances(instances)
+
+
 def _batch_verify(self, instances, alpha_seed, alpha_skip=0, want_point=False):
-    """batch_verify; instances: list of (scenario, params, proof_bytes, commitments, publics).  Returns (status, timing[4])
-    or (status, timing, check_point) when want_point (proof-sharded multi-GPU use, see parallel.py)."""
-    n = len(instances)
-    scen = (C.c_int * n)(*[i[0] for i in instances])
-    prm = np.concatenate([_prm(i[1]) for i in instances])
-    proofs = b"".join(i[2] for i in instances)
-    plens = (C.c_size_t * n)(*[len(i[2]) for i in instances])
-    cms = np.ascontiguousarray(np.concatenate([np.asarray(i[3], dtype=np.uint64).reshape(-1, 8) for i in instances]))
-    ms = (C.c_size_t * n)(*[len(np.asarray(i[3]).reshape(-1, 8)) for i in instances])
-    pubs_l = [np.asarray(i[4], dtype=np.uint64).reshape(-1, 4) for i in instances]
-    pubs = np.ascontiguousarray(np.concatenate(pubs_l + [np.zeros((1, 4), dtype=np.uint64)]))
-    npubs = (C.c_size_t * n)(*[len(p) for p in pubs_l])
+    """batch_verify; instances: list of (scenario, params, proof_bytes, commitments, publics) or a PackedInstances.  Returns
+    (status, timing[5]) or (status, timing, check_point) when want_point (proof-sharded multi-GPU use, see parallel.py)."""
+    pk = instances if isinstance(instances, PackedInstances) else PackedInstances(instances)
     timing = (C.c_double * 5)()
     pt = np.zeros(8, dtype=np.uint64)
-    rc = lib().bp_r1cs_batch_verify_scenarios(self.ctx, C.c_size_t(n), scen, ptr(prm), proofs, plens, ptr(cms), ms, ptr(pubs), npubs, bytes(alpha_seed), timing,
-                                              C.c_size_t(alpha_skip), ptr(pt))
+    rc = lib().bp_r1cs_batch_verify_scenarios(self.ctx, C.c_size_t(pk.n), pk.scen, ptr(pk.prm), pk.proofs, pk.plens, ptr(pk.cms), pk.ms, ptr(pk.pubs), pk.npubs,
+                                              bytes(alpha_seed), timing, C.c_size_t(alpha_skip), ptr(pt))
     if want_point:
         return rc, list(timing), pt
     return rc, list(timing)

@@ -166,8 +166,10 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src);
  * BP_E_VERIFICATION / BP_E_FORMAT / BP_E_GENS_LENGTH exactly where the reference returns the matching R1CSError.
  * bp_r1cs_batch_verify_scenarios replaces `batch_verify(prng, instances, pc_gens, bp_gens)` (:604-691):
  * `count` instances with concatenated proofs / commitments / publics, params 8 u64 per instance; the per-proof
- * alpha is `Fr::rand` of a ChaCha20 rng seeded with alpha_seed.  timing[5] (s): [0] verification total, [1] host transcript
- * replay, [2] GPU scalar accumulation, [3] final MSM, [4] proof decoding (point decompression) + statement replay.  Proof-sharded multi-GPU use: rank r passes its slice of the instances, alpha_skip = number
+ * alpha is `Fr::rand` of a ChaCha20 rng seeded with alpha_seed.  The instances go through in blocks: the host replays the
+ * transcripts of one block while the GPU evaluates the previous one.  timing[5] (s): [0] the whole call, [1] host replay
+ * inside the block loop (overlapped with the GPU), [2] wait for the GPU after the last block + tail scaling, [3] final MSM,
+ * [4] proof decoding (framing + point decompression).  Proof-sharded multi-GPU use: rank r passes its slice of the instances, alpha_skip = number
  * of instances on lower ranks (their alphas are drawn and discarded), and receives the affine value of ITS mega-check
  * in check_point_xy (may be NULL); the batch is valid iff the sum of all ranks' points is the identity
  * (bp_host_points_sum after an all-gather) — by linearity that sum is the reference's single MSM (:685). */
