@@ -80,9 +80,12 @@ struct Words8 {
 };
 // x^e from a table of x^(2^k) (resident words), e < 2^32
 template <class F> __device__ __forceinline__ Fe pow_table(const u32* __restrict__ tab, u32 e) {
-    Fe r = fe_one<F>();
+    if (!e) return fe_one<F>();
+    int k = __ffs((int)e) - 1;
+    Fe r = load_fe_dev<F>(tab + (size_t)k * 8);   // the lowest set bit costs a load, not a product
+    e >>= k + 1; k++;
 #pragma unroll 1
-    for (int k = 0; e; k++, e >>= 1)
+    for (; e; k++, e >>= 1)
         if (e & 1) r = fe_mul<F>(r, load_fe_dev<F>(tab + (size_t)k * 8));
     return r;
 }

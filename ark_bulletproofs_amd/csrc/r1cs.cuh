@@ -165,6 +165,9 @@ struct VfyTemplateDev {
     const u32* ent_q;        // constraint index per entry
     const u32* ent_c;        // coefficient id per entry
     const u32* coefs;        // resident words
+    const u32* m_off;        // n+1: per multiplier index i, the entries of W_L, W_R, W_O columns i merged and sorted by constraint
+    const u32* m_ent;        // (vector << 30) | constraint index q     (vector 0 = W_L, 1 = W_R, 2 = W_O)
+    const u32* m_c;          // coefficient id per merged entry
     const u32* const_q;      // constant terms (Variable::One) of the constraints: wc = -sum z^(q+1) * coef  (verifier.rs:339-341)
     const u32* const_c;
     u32 n_const;
@@ -172,20 +175,49 @@ struct VfyTemplateDev {
 static constexpr u32 VFY_PB_WORDS = 832;  // ztab[32] | yinv_tab[32] | consts[8]: allinv,x,a,b,u,alpha,coefD,- | u_sq[31] | pad
 static constexpr u32 VFY_PB_SCALARS = VFY_PB_WORDS / 8;
 
-template <class F> __device__ __forceinline__ Fe csc_column(const VfyTemplateDev& t, int vec, u32 i, const u32* __restrict__ ztab) {
-    Fe acc = fe_zero<F>();
-    const u32 b = t.col_off[vec][i], e = t.col_off[vec][i + 1];
-    for (u32 k = b; k < e; k++) {
-        const Fe zq = pow_table<F>(ztab, t.ent_q[k] + 1);   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
-        acc = fe_addr<F>(acc, fe_mul<F>(zq, load_fe_dev<F>(t.coefs + (size_t)t.ent_c[k] * 8)));
+// Per-proof split tables for k_vfy_batch.  With i = hi * 2^LOB + lo:
+//   s[i]       = allinv * prod_{bit j of i set} u_sq[k-1-j]      = s_lo[lo] * s_hi[hi]     (inner_product_proof.rs:302-311 in closed form)
+//   s[N-1-i]   = allinv * prod_{bit j of i clear} u_sq[k-1-j]    = r_lo[lo] * r_hi[hi]
+//   y^-i                                                          = y_lo[lo] * y_hi[hi]
+// so the batch kernel pays 3 products per (proof, i) instead of ~k + k/2.  Layout per proof: 3 x (2^LOB + 2^HIB) resident scalars,
+// [s_lo | s_hi | r_lo | r_hi | y_lo | y_hi].  grid (ceil(2^max(LOB,HIB) / 256), P).
+template <class C> __global__ void __launch_bounds__(256)
+k_vfy_tables(const u32* __restrict__ params, u32 P, u32 k, u32 LOB, u32* __restrict__ tables) {
+    typedef typename C::Fr F;
+    const u32 tIdx = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+    if (p >= P) return;
+    const u32 HIB = k - LOB, nlo = 1u << LOB, nhi = 1u << HIB;
+    const u32* pb = params + (size_t)p * VFY_PB_WORDS;
+    const u32* ytab = pb + 256;
+    const u32* cst = pb + 512;
+    const u32* usq = pb + 576;
+    u32* T = tables + (size_t)p * 3 * (nlo + nhi) * 8;
+    if (tIdx < nlo) {
+        Fe s = load_fe_dev<F>(cst), r = s;
+        for (u32 j = 0; j < LOB; j++) {
+            const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - j) * 8);
+            if ((tIdx >> j) & 1) s = fe_mul<F>(s, q); else r = fe_mul<F>(r, q);
+        }
+        store_fe_dev<F>(T + (size_t)tIdx * 8, s);
+        store_fe_dev<F>(T + (size_t)(nlo + nhi + tIdx) * 8, r);
+        store_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + tIdx) * 8, pow_table<F>(ytab, tIdx));
     }
-    return acc;
+    if (tIdx < nhi) {
+        Fe s = fe_one<F>(), r = s;
+        for (u32 j = 0; j < HIB; j++) {
+            const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - (LOB + j)) * 8);
+            if ((tIdx >> j) & 1) s = fe_mul<F>(s, q); else r = fe_mul<F>(r, q);
+        }
+        store_fe_dev<F>(T + (size_t)(nlo + tIdx) * 8, s);
+        store_fe_dev<F>(T + (size_t)(nlo + nhi + nlo + tIdx) * 8, r);
+        store_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + nlo + tIdx) * 8, pow_table<F>(ytab, tIdx << LOB));
+    }
 }
 
 // grid (ceil(N/256), nchunks).  g_part/h_part: [nchunks][N] resident words; d_part: [nchunks * gridDim.x] resident words.
 template <class C> __global__ void __launch_bounds__(256)
 k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chunk, u32 n, u32 N, u32 k, u32* __restrict__ g_part,
-            u32* __restrict__ h_part, u32* __restrict__ d_part) {
+            u32* __restrict__ h_part, u32* __restrict__ d_part, const u32* __restrict__ tables, u32 LOB) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,16 +233,26 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chu
             const u32* usq = pb + 576;
             const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
             const Fe alpha = load_fe_dev<F>(cst + 40);
-            Fe s_i = allinv, s_rev = allinv;
-#pragma unroll 1
-            for (u32 j = 0; j < k; j++) {
-                const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - j) * 8);
-                if ((i >> j) & 1) s_i = fe_mul<F>(s_i, q); else s_rev = fe_mul<F>(s_rev, q);
-            }
-            const Fe yni = pow_table<F>(ytab, i);
+            const u32 nlo = 1u << LOB, nhi = 1u << (k - LOB), lo = i & (nlo - 1u), hi = i >> LOB;
+            const u32* T = tables + (size_t)p * 3 * (nlo + nhi) * 8;
+            const Fe s_i = fe_mul<F>(load_fe_dev<F>(T + (size_t)lo * 8), load_fe_dev<F>(T + (size_t)(nlo + hi) * 8));
+            const Fe s_rev = fe_mul<F>(load_fe_dev<F>(T + (size_t)(nlo + nhi + lo) * 8), load_fe_dev<F>(T + (size_t)(nlo + nhi + nlo + hi) * 8));
+            const Fe yni = fe_mul<F>(load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + lo) * 8), load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * 8));
+            (void)allinv; (void)usq; (void)ytab;
             Fe g, h;
             if (i < n) {
-                const Fe wL = csc_column<F>(t, 0, i, ztab), wR = csc_column<F>(t, 1, i, ztab), wO = csc_column<F>(t, 2, i, ztab);
+                // columns i of W_L, W_R, W_O in one pass over their entries sorted by constraint index: z^(q+1) is carried
+                // from entry to entry (a product with z^(dq), dq small) instead of being rebuilt from the power table
+                Fe wL = fe_zero<F>(), wR = fe_zero<F>(), wO = fe_zero<F>(), zp = fe_one<F>();
+                u32 cur = 0;
+                for (u32 e = t.m_off[i], e1 = t.m_off[i + 1]; e < e1; e++) {
+                    const u32 ent = t.m_ent[e], q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
+                    if (cur == 0) zp = pow_table<F>(ztab, q1);
+                    else if (q1 != cur) zp = fe_mul<F>(zp, pow_table<F>(ztab, q1 - cur));
+                    cur = q1;
+                    const Fe term = fe_mul<F>(zp, load_fe_dev<F>(t.coefs + (size_t)t.m_c[e] * 8));
+                    if (vec == 0) wL = fe_addr<F>(wL, term); else if (vec == 1) wR = fe_addr<F>(wR, term); else wO = fe_addr<F>(wO, term);
+                }
                 const Fe ywR = fe_mul<F>(yni, wR);
                 g = fe_sub<F, 2>(fe_mul<F>(x, ywR), fe_mul<F>(a, s_i));
                 Fe tt = fe_addr<F>(fe_mul<F>(x, wL), wO);
