@@ -59,6 +59,23 @@ struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+struct IpaState {
+    const u32 *d_Q = nullptr, *d_Gf = nullptr, *d_Hf = nullptr;
+    u32 *d_G = nullptr, *d_H = nullptr, *d_a = nullptr, *d_b = nullptr;
+    size_t n = 0;            // current vector length
+    size_t round = 0;
+    bool first = true;
+    // pending common factors of the resident generator vectors: G_true = gamma_G * Ghat, H_true = gamma_H * Hhat
+    F4 gamma_G, gamma_H;
+    bool pending = false, h_geo = false;  // h_geo: H_true[i] = gamma_H * rho^i * Hhat[i]
+    // optional hints of the R1CS prover (see ipa_create_dev)
+    bool have_gf = false, have_rho = false;
+    F4 gf_halves[2];
+    const F4* rho_pw = nullptr;
+    const u32* d_rho_pow = nullptr;
+    bool lr_done = false;
+};
+
 struct bp_ctx {
     int curve = 0, device = 0;
     hipStream_t stream = nullptr;
@@ -84,6 +101,8 @@ struct bp_ctx {
     size_t h_vstage_cap[2] = {0, 0};
     hipEvent_t vstage_ev[2] = {nullptr, nullptr};
     std::map<std::string, std::shared_ptr<void>> templates;
+    IpaState ipa_step;         // bp_ipa_begin .. bp_ipa_finish
+    bool ipa_step_active = false;
     u32* h_totals = nullptr;  // pinned
     u32* h_T = nullptr;       // pinned
     size_t h_T_cap = 0;
@@ -453,102 +472,123 @@ template <class C> static int launch_uniform_fold(bp_ctx* ctx, u32* d_G, u32* d_
     return BP_OK;
 }
 
-template <class C>
-static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b, size_t n,
-                          const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4],
-                          const F4* gf_halves = nullptr /* optional hint: G_factors == gf_halves[0] on [0,n/2) and gf_halves[1] on [n/2,n) */,
-                          const F4* rho_pw = nullptr /* optional hint (with gf_halves): H_factors[i] = rho^i * G_factors[i];
-                                                        rho_pw[k] = rho^-(2^k), rho_pw[32+k] = rho^(2^k), k < 32 */,
-                          const u32* d_rho_pow = nullptr /* device table of rho^(2^k), resident words */) {
+// State of one InnerProductProof::create in flight (the loop body of src/inner_product_proof.rs:70-237 cut at the Fiat-Shamir
+// step): ipa_round_lr computes L, R of the current round, ipa_round_fold consumes the challenge.  ipa_create_dev drives it with a
+// callback; bp_ipa_begin / bp_ipa_round_LR / bp_ipa_round_fold / bp_ipa_finish expose the same steps for hosts that keep the
+// transcript on their side of the boundary, and for the index-cyclic multi-GPU partition (parallel.py), where L and R of a
+// round are sums of per-rank partials.
+static inline int ipa_lg2(size_t x) { int k = 0; while (((size_t)1 << k) < x) k++; return k; }
+
+template <class C> static int ipa_begin_dev(bp_ctx* ctx, IpaState& s, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b,
+                                            size_t n, const F4* gf_halves, const F4* rho_pw, const u32* d_rho_pow) {
     typedef host::Fld<typename C::Fr> S;
-    typedef host::Grp<C> G;
     if (n == 0 || (n & (n - 1))) { g_err = "ipa_create: n must be a power of two (reference asserts, src/inner_product_proof.rs:66)"; return BP_E_ARG; }
-    hipStream_t st = ctx->stream;
+    s = IpaState();
+    s.d_Q = d_Q; s.d_Gf = d_Gf; s.d_Hf = d_Hf; s.d_G = d_G; s.d_H = d_H; s.d_a = d_a; s.d_b = d_b; s.n = n;
+    s.gamma_G = S::one(); s.gamma_H = S::one();
+    if (gf_halves) { s.have_gf = true; s.gf_halves[0] = gf_halves[0]; s.gf_halves[1] = gf_halves[1]; }
+    if (rho_pw && d_rho_pow) { s.have_rho = true; s.rho_pw = rho_pw; s.d_rho_pow = d_rho_pow; }
     BPCHK(ctx->ipa_sL.ensure((n + 1) * 32));
     BPCHK(ctx->ipa_sR.ensure((n + 1) * 32));
     BPCHK(ctx->ipa_part.ensure(((n / 2 + 255) / 256 + 1) * 64));
-    bool first = true;
-    size_t round = 0;
-    // pending common factors of the resident generator vectors: G_true = gamma_G * Ghat, H_true = gamma_H * Hhat
-    F4 gamma_G = S::one(), gamma_H = S::one();
-    bool pending = false, h_geo = false;  // h_geo: H_true[i] = gamma_H * rho^i * Hhat[i]
-    auto lg2 = [](size_t x) { int k = 0; while (((size_t)1 << k) < x) k++; return k; };
-    while (n != 1) {
-        n /= 2;
-        const u32 gb = (u32)((n + 255) / 256);
-        u32* sL = ctx->ipa_sL.as<u32>();
-        u32* sR = ctx->ipa_sR.as<u32>();
-        {
-            ScopedK tk(ctx, BP_K_IPA_SCALARS);
-            hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, d_Gf, d_Hf, first ? 1 : 0, (u32)n, sL, sR, ctx->ipa_part.as<u32>(),
-                               pending ? (h_geo ? 2 : 1) : 0, words_of<S>(gamma_G), words_of<S>(gamma_H), d_rho_pow);
-            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8);
-        }
-        BaseSegs sg; memset(&sg, 0, sizeof sg);
-        sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n; sg.start[2] = (u32)(2 * n); sg.start[3] = (u32)(2 * n + 1);
-        sg.ptr[0] = d_G + n * 16; sg.ptr[1] = d_H; sg.ptr[2] = d_Q;
-        J4 Lj, Rj;
-        BPCHK(msm_run<C>(ctx, sg, sL, 2 * n + 1, 0, Lj));
-        sg.ptr[0] = d_G; sg.ptr[1] = d_H + n * 16;
-        BPCHK(msm_run<C>(ctx, sg, sR, 2 * n + 1, 0, Rj));
-        A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
-        uint64_t Lw[8], Rw[8], uw[4];
-        memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
-        memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
-        memcpy(L_out + 8 * round, Lw, 64); memcpy(R_out + 8 * round, Rw, 64);
-        int rc = challenge(Lw, Rw, uw);
-        if (rc) { g_err = "ipa_create: challenge callback failed"; return rc < 0 ? rc : BP_E_ARG; }
-        F4 u; memcpy(u.v, uw, 32);
-        F4 ui = S::inv(u);
-        {
-            ScopedK tk(ctx, BP_K_IPA_FOLD);
-            hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, d_a, d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
-            if (first && gf_halves && rho_pw && d_rho_pow && !gf_halves[0].is_zero() && !gf_halves[1].is_zero()) {
-                // both halves uniform.  G as below.  H: u*gL*rho^i*H_L + u^-1*gR*rho^(n+i)*H_R = (u^-1*gR*rho^n) * rho^i * (H_R + t*H_L),
-                // t = u^2 * (gL/gR) * rho^-n: the pending factor of H stays geometric, K * rho^i.
-                const int k = lg2(n);
-                const F4 s2 = S::mul(u, gf_halves[1]);
-                const F4 ginv = S::inv(gf_halves[1]);
-                BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, S::mul(S::mul(ui, gf_halves[0]), S::inv(s2)),
-                                             S::mul(S::mul(S::sqr(u), S::mul(gf_halves[0], ginv)), rho_pw[k]), 3));
-                gamma_G = S::mul(gamma_G, s2);
-                gamma_H = S::mul(S::mul(ui, gf_halves[1]), rho_pw[32 + k]);
-                pending = true; h_geo = true;
-            } else if (first && gf_halves && !gf_halves[0].is_zero() && !gf_halves[1].is_zero()) {
-                // G: u^-1*gL*G_L + u*gR*G_R = (u*gR) * (G_R + t*G_L), t = u^-1*gL / (u*gR): uniform, one NAF ladder; H: per-lane factors
-                const F4 s2 = S::mul(u, gf_halves[1]);
-                const F4 tG = S::mul(S::mul(ui, gf_halves[0]), S::inv(s2));
-                BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, tG, tG, 1));
-                FoldFinish ff;
-                BPCHK(fold_finish_plan(ctx, n, ff));
-                hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u), words_of<S>(ui), 2, ff.jac);
-                fold_finish_launch<C>(st, ff, d_G, d_H, n, 2, n);
-                gamma_G = S::mul(gamma_G, s2);
-                pending = true;
-            } else if (first) {
-                FoldFinish ff;
-                BPCHK(fold_finish_plan(ctx, 2 * n, ff));
-                hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, d_Gf, d_Hf, 1, (u32)n, words_of<S>(u),
-                                   words_of<S>(ui), 3, ff.jac);
-                fold_finish_launch<C>(st, ff, d_G, d_H, n, 3, 2 * n);
-            } else {
-                // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
-                // (geometric pending factor: c[i]/c[n+i] = rho^-n joins t, and K picks up rho^n)
-                const int k = lg2(n);
-                BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, S::sqr(ui), h_geo ? S::mul(S::sqr(u), rho_pw[k]) : S::sqr(u), 3));
-                gamma_G = S::mul(gamma_G, u);
-                gamma_H = h_geo ? S::mul(S::mul(gamma_H, ui), rho_pw[32 + k]) : S::mul(gamma_H, ui);
-                pending = true;
-            }
-        }
-        HIPCHK(hipGetLastError());
-        first = false;
-        round++;
+    return BP_OK;
+}
+// L, R of the current round (affine, ark layout): src/inner_product_proof.rs:78-131 (first round) / :166-213
+template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw[8], uint64_t Rw[8]) {
+    typedef host::Fld<typename C::Fr> S;
+    typedef host::Grp<C> G;
+    if (s.n <= 1 || s.lr_done) { g_err = "ipa: round_LR out of sequence"; return BP_E_ARG; }
+    hipStream_t st = ctx->stream;
+    const size_t n = s.n / 2;
+    const u32 gb = (u32)((n + 255) / 256);
+    u32* sL = ctx->ipa_sL.as<u32>();
+    u32* sR = ctx->ipa_sR.as<u32>();
+    {
+        ScopedK tk(ctx, BP_K_IPA_SCALARS);
+        hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, s.d_Gf, s.d_Hf, s.first ? 1 : 0, (u32)n, sL, sR, ctx->ipa_part.as<u32>(),
+                           s.pending ? (s.h_geo ? 2 : 1) : 0, words_of<S>(s.gamma_G), words_of<S>(s.gamma_H), s.d_rho_pow);
+        hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8);
     }
-    // a[0], b[0] -> ark layout on the host
+    BaseSegs sg; memset(&sg, 0, sizeof sg);
+    sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n; sg.start[2] = (u32)(2 * n); sg.start[3] = (u32)(2 * n + 1);
+    sg.ptr[0] = s.d_G + n * 16; sg.ptr[1] = s.d_H; sg.ptr[2] = s.d_Q;
+    J4 Lj, Rj;
+    BPCHK(msm_run<C>(ctx, sg, sL, 2 * n + 1, 0, Lj));
+    sg.ptr[0] = s.d_G; sg.ptr[1] = s.d_H + n * 16;
+    BPCHK(msm_run<C>(ctx, sg, sR, 2 * n + 1, 0, Rj));
+    A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
+    memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
+    memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
+    s.lr_done = true;
+    return BP_OK;
+}
+// the folds of the round for challenge u (ark words): :137-155 (first round) / :214-224
+template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uint64_t uw[4]) {
+    typedef host::Fld<typename C::Fr> S;
+    if (!s.lr_done) { g_err = "ipa: round_fold before round_LR"; return BP_E_ARG; }
+    hipStream_t st = ctx->stream;
+    const size_t n = s.n / 2;
+    const u32 gb = (u32)((n + 255) / 256);
+    u32 *d_G = s.d_G, *d_H = s.d_H;
+    const bool first = s.first;
+    F4 u; memcpy(u.v, uw, 32);
+    F4 ui = S::inv(u);
+    {
+        ScopedK tk(ctx, BP_K_IPA_FOLD);
+        hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
+        const bool gf_ok = first && s.have_gf && !s.gf_halves[0].is_zero() && !s.gf_halves[1].is_zero();
+        if (gf_ok && s.have_rho) {
+            // both halves uniform.  G as below.  H: u*gL*rho^i*H_L + u^-1*gR*rho^(n+i)*H_R = (u^-1*gR*rho^n) * rho^i * (H_R + t*H_L),
+            // t = u^2 * (gL/gR) * rho^-n: the pending factor of H stays geometric, K * rho^i.
+            const int k = ipa_lg2(n);
+            const F4 s2 = S::mul(u, s.gf_halves[1]);
+            const F4 ginv = S::inv(s.gf_halves[1]);
+            BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, S::mul(S::mul(ui, s.gf_halves[0]), S::inv(s2)),
+                                         S::mul(S::mul(S::sqr(u), S::mul(s.gf_halves[0], ginv)), s.rho_pw[k]), 3));
+            s.gamma_G = S::mul(s.gamma_G, s2);
+            s.gamma_H = S::mul(S::mul(ui, s.gf_halves[1]), s.rho_pw[32 + k]);
+            s.pending = true; s.h_geo = true;
+        } else if (gf_ok) {
+            // G: u^-1*gL*G_L + u*gR*G_R = (u*gR) * (G_R + t*G_L), t = u^-1*gL / (u*gR): uniform, one NAF ladder; H: per-lane factors
+            const F4 s2 = S::mul(u, s.gf_halves[1]);
+            const F4 tG = S::mul(S::mul(ui, s.gf_halves[0]), S::inv(s2));
+            BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, tG, tG, 1));
+            FoldFinish ff;
+            BPCHK(fold_finish_plan(ctx, n, ff));
+            hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, s.d_Gf, s.d_Hf, 1, (u32)n, words_of<S>(u), words_of<S>(ui), 2, ff.jac);
+            fold_finish_launch<C>(st, ff, d_G, d_H, n, 2, n);
+            s.gamma_G = S::mul(s.gamma_G, s2);
+            s.pending = true;
+        } else if (first) {
+            FoldFinish ff;
+            BPCHK(fold_finish_plan(ctx, 2 * n, ff));
+            hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, s.d_Gf, s.d_Hf, 1, (u32)n, words_of<S>(u),
+                               words_of<S>(ui), 3, ff.jac);
+            fold_finish_launch<C>(st, ff, d_G, d_H, n, 3, 2 * n);
+        } else {
+            // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
+            // (geometric pending factor: c[i]/c[n+i] = rho^-n joins t, and K picks up rho^n)
+            const int k = ipa_lg2(n);
+            BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, S::sqr(ui), s.h_geo ? S::mul(S::sqr(u), s.rho_pw[k]) : S::sqr(u), 3));
+            s.gamma_G = S::mul(s.gamma_G, u);
+            s.gamma_H = s.h_geo ? S::mul(S::mul(s.gamma_H, ui), s.rho_pw[32 + k]) : S::mul(s.gamma_H, ui);
+            s.pending = true;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    s.first = false;
+    s.round++;
+    s.n = n;
+    s.lr_done = false;
+    return BP_OK;
+}
+// a[0], b[0] -> ark layout on the host (:226-231)
+template <class C> static int ipa_finish_dev(bp_ctx* ctx, IpaState& s, uint64_t a_out[4], uint64_t b_out[4]) {
+    if (s.n != 1) { g_err = "ipa: finish before the last round"; return BP_E_ARG; }
+    hipStream_t st = ctx->stream;
     BPCHK(ctx->io_out.ensure(64));
-    hipLaunchKernelGGL(k_scalars_export<typename C::Fr>, dim3(1), dim3(64), 0, st, d_a, ctx->io_out.as<u32>(), 1u);
-    hipLaunchKernelGGL(k_scalars_export<typename C::Fr>, dim3(1), dim3(64), 0, st, d_b, ctx->io_out.as<u32>() + 8, 1u);
+    hipLaunchKernelGGL(k_scalars_export<typename C::Fr>, dim3(1), dim3(64), 0, st, s.d_a, ctx->io_out.as<u32>(), 1u);
+    hipLaunchKernelGGL(k_scalars_export<typename C::Fr>, dim3(1), dim3(64), 0, st, s.d_b, ctx->io_out.as<u32>() + 8, 1u);
     uint64_t ab[8];
     HIPCHK(hipMemcpyAsync(ab, ctx->io_out.p, 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -558,10 +598,32 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
     return BP_OK;
 }
 
+// ---- InnerProductProof::create orchestration (src/inner_product_proof.rs:37-239): all vectors device-resident in the engine's
+// layouts and consumed (folded in place), like the reference's by-value Vec arguments.
 template <class C>
-static int ipa_create_host_entry(bp_ctx* ctx, const uint64_t* Q, const uint64_t* Gf, const uint64_t* Hf, const uint64_t* Gv, const uint64_t* Hv,
-                                 const uint64_t* a, const uint64_t* b, size_t n, const ChallengeFn& fn, uint64_t* L_out, uint64_t* R_out,
-                                 uint64_t* a_out, uint64_t* b_out) {
+static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b, size_t n,
+                          const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4],
+                          const F4* gf_halves = nullptr /* optional hint: G_factors == gf_halves[0] on [0,n/2) and gf_halves[1] on [n/2,n) */,
+                          const F4* rho_pw = nullptr /* optional hint (with gf_halves): H_factors[i] = rho^i * G_factors[i];
+                                                        rho_pw[k] = rho^-(2^k), rho_pw[32+k] = rho^(2^k), k < 32 */,
+                          const u32* d_rho_pow = nullptr /* device table of rho^(2^k), resident words */) {
+    IpaState s;
+    BPCHK(ipa_begin_dev<C>(ctx, s, d_Q, d_Gf, d_Hf, d_G, d_H, d_a, d_b, n, gf_halves, rho_pw, d_rho_pow));
+    while (s.n != 1) {
+        uint64_t Lw[8], Rw[8], uw[4];
+        BPCHK(ipa_round_lr<C>(ctx, s, Lw, Rw));
+        memcpy(L_out + 8 * s.round, Lw, 64); memcpy(R_out + 8 * s.round, Rw, 64);
+        int rc = challenge(Lw, Rw, uw);
+        if (rc) { g_err = "ipa_create: challenge callback failed"; return rc < 0 ? rc : BP_E_ARG; }
+        BPCHK(ipa_round_fold<C>(ctx, s, uw));
+    }
+    return ipa_finish_dev<C>(ctx, s, a_out, b_out);
+}
+
+// uploads the host vectors of an IPA instance into the ctx's working buffers (engine layouts)
+template <class C>
+static int ipa_upload_host(bp_ctx* ctx, const uint64_t* Q, const uint64_t* Gf, const uint64_t* Hf, const uint64_t* Gv, const uint64_t* Hv, const uint64_t* a,
+                           const uint64_t* b, size_t n) {
     typedef typename C::Fr Fr;
     hipStream_t st = ctx->stream;
     BPCHK(ctx->ipa_G.ensure(n * 64)); BPCHK(ctx->ipa_H.ensure(n * 64));
@@ -582,8 +644,52 @@ static int ipa_create_host_entry(bp_ctx* ctx, const uint64_t* Q, const uint64_t*
     DevBuf* sc[] = {&ctx->ipa_a, &ctx->ipa_b, &ctx->ipa_Gf, &ctx->ipa_Hf};
     for (auto s : sc) hipLaunchKernelGGL(k_scalars_import<Fr>, dim3(gb), dim3(256), 0, st, s->as<u32>(), s->as<u32>(), (u32)n);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));   // the host buffers are the caller's: done with them before returning
+    return BP_OK;
+}
+template <class C>
+static int ipa_create_host_entry(bp_ctx* ctx, const uint64_t* Q, const uint64_t* Gf, const uint64_t* Hf, const uint64_t* Gv, const uint64_t* Hv,
+                                 const uint64_t* a, const uint64_t* b, size_t n, const ChallengeFn& fn, uint64_t* L_out, uint64_t* R_out,
+                                 uint64_t* a_out, uint64_t* b_out) {
+    BPCHK(ipa_upload_host<C>(ctx, Q, Gf, Hf, Gv, Hv, a, b, n));
     return ipa_create_dev<C>(ctx, ctx->ipa_Q.as<u32>(), ctx->ipa_Gf.as<u32>(), ctx->ipa_Hf.as<u32>(), ctx->ipa_G.as<u32>(), ctx->ipa_H.as<u32>(),
                              ctx->ipa_a.as<u32>(), ctx->ipa_b.as<u32>(), n, fn, L_out, R_out, a_out, b_out);
+}
+template <class C>
+static int ipa_begin_host_entry(bp_ctx* ctx, const uint64_t* Q, const uint64_t* Gf, const uint64_t* Hf, const uint64_t* Gv, const uint64_t* Hv,
+                                const uint64_t* a, const uint64_t* b, size_t n) {
+    ctx->ipa_step_active = false;
+    if (n == 0 || (n & (n - 1))) { g_err = "ipa_begin: n must be a power of two (reference asserts, src/inner_product_proof.rs:66)"; return BP_E_ARG; }
+    BPCHK(ipa_upload_host<C>(ctx, Q, Gf, Hf, Gv, Hv, a, b, n));
+    BPCHK(ipa_begin_dev<C>(ctx, ctx->ipa_step, ctx->ipa_Q.as<u32>(), ctx->ipa_Gf.as<u32>(), ctx->ipa_Hf.as<u32>(), ctx->ipa_G.as<u32>(), ctx->ipa_H.as<u32>(),
+                           ctx->ipa_a.as<u32>(), ctx->ipa_b.as<u32>(), n, nullptr, nullptr, nullptr));
+    ctx->ipa_step_active = true;
+    return BP_OK;
+}
+// current a, b, G, H (first n_cur elements, ark layout) and the pending factors: G_true[i] = gamma_G * G[i], H_true[i] = gamma_H * H[i]
+template <class C>
+static int ipa_export_host(bp_ctx* ctx, uint64_t* a, uint64_t* b, uint64_t* G_xy, uint64_t* H_xy, uint64_t gG[4], uint64_t gH[4], size_t* n_cur) {
+    typedef typename C::Fr Fr;
+    IpaState& s = ctx->ipa_step;
+    if (s.lr_done) { g_err = "ipa_export: between round_LR and round_fold"; return BP_E_ARG; }
+    hipStream_t st = ctx->stream;
+    const size_t n = s.n;
+    const u32 gb = (u32)((n + 255) / 256);
+    BPCHK(ctx->io_out.ensure(n * 64 * 2 + n * 32 * 2));
+    u32* o = ctx->io_out.as<u32>();
+    hipLaunchKernelGGL(k_points_dev_to_ark<C>, dim3(gb), dim3(256), 0, st, s.d_G, o, (u32)n);
+    hipLaunchKernelGGL(k_points_dev_to_ark<C>, dim3(gb), dim3(256), 0, st, s.d_H, o + n * 16, (u32)n);
+    hipLaunchKernelGGL(k_scalars_export<Fr>, dim3(gb), dim3(256), 0, st, s.d_a, o + n * 32, (u32)n);
+    hipLaunchKernelGGL(k_scalars_export<Fr>, dim3(gb), dim3(256), 0, st, s.d_b, o + n * 40, (u32)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(G_xy, o, n * 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(H_xy, o + n * 16, n * 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a, o + n * 32, n * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(b, o + n * 40, n * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(gG, s.gamma_G.v, 32); memcpy(gH, s.gamma_H.v, 32);
+    *n_cur = n;
+    return BP_OK;
 }
 
 #include "r1cs_host.inc"
@@ -826,6 +932,40 @@ int bp_ipa_create(bp_ctx* c, const uint64_t Q_xy[8], const uint64_t* G_factors, 
     ChallengeFn fn = [cb, user](const uint64_t* L, const uint64_t* R, uint64_t* u) { return cb(user, L, R, u); };
     return c->curve == 0 ? ipa_create_host_entry<Secq>(c, Q_xy, G_factors, H_factors, G_xy, H_xy, a, b, n, fn, L_out_xy, R_out_xy, a_out, b_out)
                          : ipa_create_host_entry<Zorro>(c, Q_xy, G_factors, H_factors, G_xy, H_xy, a, b, n, fn, L_out_xy, R_out_xy, a_out, b_out);
+}
+
+int bp_ipa_begin(bp_ctx* c, const uint64_t Q_xy[8], const uint64_t* G_factors, const uint64_t* H_factors, const uint64_t* G_xy, const uint64_t* H_xy,
+                 const uint64_t* a, const uint64_t* b, size_t n) {
+    if (!c || !Q_xy || !G_factors || !H_factors || !G_xy || !H_xy || !a || !b) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? ipa_begin_host_entry<Secq>(c, Q_xy, G_factors, H_factors, G_xy, H_xy, a, b, n)
+                         : ipa_begin_host_entry<Zorro>(c, Q_xy, G_factors, H_factors, G_xy, H_xy, a, b, n);
+}
+int bp_ipa_round_LR(bp_ctx* c, uint64_t L_xy[8], uint64_t R_xy[8]) {
+    if (!c || !L_xy || !R_xy) return BP_E_ARG;
+    if (!c->ipa_step_active) { g_err = "bp_ipa_round_LR: no bp_ipa_begin"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? ipa_round_lr<Secq>(c, c->ipa_step, L_xy, R_xy) : ipa_round_lr<Zorro>(c, c->ipa_step, L_xy, R_xy);
+}
+int bp_ipa_round_fold(bp_ctx* c, const uint64_t u[4]) {
+    if (!c || !u) return BP_E_ARG;
+    if (!c->ipa_step_active) { g_err = "bp_ipa_round_fold: no bp_ipa_begin"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? ipa_round_fold<Secq>(c, c->ipa_step, u) : ipa_round_fold<Zorro>(c, c->ipa_step, u);
+}
+int bp_ipa_finish(bp_ctx* c, uint64_t a[4], uint64_t b[4]) {
+    if (!c || !a || !b) return BP_E_ARG;
+    if (!c->ipa_step_active) { g_err = "bp_ipa_finish: no bp_ipa_begin"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = c->curve == 0 ? ipa_finish_dev<Secq>(c, c->ipa_step, a, b) : ipa_finish_dev<Zorro>(c, c->ipa_step, a, b);
+    if (rc == BP_OK) c->ipa_step_active = false;
+    return rc;
+}
+int bp_ipa_export(bp_ctx* c, uint64_t* a, uint64_t* b, uint64_t* G_xy, uint64_t* H_xy, uint64_t gamma_G[4], uint64_t gamma_H[4], size_t* n_cur) {
+    if (!c || !a || !b || !G_xy || !H_xy || !gamma_G || !gamma_H || !n_cur) return BP_E_ARG;
+    if (!c->ipa_step_active) { g_err = "bp_ipa_export: no bp_ipa_begin"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? ipa_export_host<Secq>(c, a, b, G_xy, H_xy, gamma_G, gamma_H, n_cur) : ipa_export_host<Zorro>(c, a, b, G_xy, H_xy, gamma_G, gamma_H, n_cur);
 }
 
 // ---- generators -------------------------------------------------------------------------------------

@@ -156,6 +156,52 @@ def _ipa_create(self, Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec, chall
 Engine.ipa_create = _ipa_create
 
 
+# InnerProductProof::create cut at the Fiat-Shamir step (bp_ipa_begin .. bp_ipa_finish): the stepping interface that
+# parallel.sharded_ipa_create drives on every rank
+def _ipa_begin(self, Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec):
+    G, H = u64arr(G_vec, 8), u64arr(H_vec, 8)
+    n = len(G)
+    arrs = [u64arr(Q, 8)] + [u64arr(x, 4) for x in (G_factors, H_factors)] + [G, H] + [u64arr(x, 4) for x in (a_vec, b_vec)]
+    for x in arrs[1:]:
+        if len(x) != n:
+            raise ValueError("ipa_begin: vector lengths differ")
+    check(lib().bp_ipa_begin(self.ctx, *[ptr(x) for x in arrs], C.c_size_t(n)), "bp_ipa_begin")
+
+
+def _ipa_round_LR(self):
+    L, R = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    check(lib().bp_ipa_round_LR(self.ctx, ptr(L), ptr(R)), "bp_ipa_round_LR")
+    return L, R
+
+
+def _ipa_round_fold(self, u):
+    u = np.ascontiguousarray(u, dtype=np.uint64).reshape(4)
+    check(lib().bp_ipa_round_fold(self.ctx, ptr(u)), "bp_ipa_round_fold")
+
+
+def _ipa_finish(self):
+    a, b = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    check(lib().bp_ipa_finish(self.ctx, ptr(a), ptr(b)), "bp_ipa_finish")
+    return a, b
+
+
+def _ipa_export(self, n_max):
+    """current (a, b, G, H, gamma_G, gamma_H); G_true = gamma_G * G, H_true = gamma_H * H"""
+    a, b = np.zeros((n_max, 4), dtype=np.uint64), np.zeros((n_max, 4), dtype=np.uint64)
+    G, H = np.zeros((n_max, 8), dtype=np.uint64), np.zeros((n_max, 8), dtype=np.uint64)
+    gG, gH = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    n = C.c_size_t(0)
+    check(lib().bp_ipa_export(self.ctx, ptr(a), ptr(b), ptr(G), ptr(H), ptr(gG), ptr(gH), C.byref(n)), "bp_ipa_export")
+    return a[: n.value], b[: n.value], G[: n.value], H[: n.value], gG, gH
+
+
+Engine.ipa_begin = _ipa_begin
+Engine.ipa_round_LR = _ipa_round_LR
+Engine.ipa_round_fold = _ipa_round_fold
+Engine.ipa_finish = _ipa_finish
+Engine.ipa_export = _ipa_export
+
+
 # ---- generators / prover ---------------------------------------------------------------------------
 SC_SHUFFLE, SC_RANGE, SC_EXAMPLE, SC_SQUARE_CHAIN, SC_MULTI_RANGE = 0, 1, 2, 3, 4
 

@@ -7,6 +7,9 @@ local (world-1)-add point-reduce).  SURVEY.md §8(e).
   window_sharded_msm    window sharding: every rank holds all terms and owns a range of Pippenger windows
   sharded_batch_verify  whole proofs per rank; by linearity the sum of the per-rank mega-check points is the
                         reference's single MSM (src/r1cs/verifier.rs:685)
+  sharded_ipa_create    InnerProductProof::create with every vector partitioned index-cyclically (rank r owns the elements
+                        i = r mod world): element i and its fold partner n/2 + i live on the same rank, so all folds are
+                        local; a round exchanges one pair of partial (L, R) points per rank
 """
 import numpy as np
 
@@ -31,6 +34,76 @@ def allgather_points(point_xy, group=None, device=None):
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(outs, t, group=group)
     return np.stack([o.cpu().numpy().view(np.uint64) for o in outs])
+
+
+def allgather_words(arr, group=None, device=None):
+    """all-gather a u64 array of identical shape on every rank -> (world, ...) array"""
+    import torch
+    import torch.distributed as dist
+
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return a.reshape((1,) + a.shape)
+    t = torch.from_numpy(a.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(outs, t, group=group)
+    return np.stack([o.cpu().numpy().view(np.uint64) for o in outs])
+
+
+def sharded_ipa_create(curve, stepper, Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec, challenge, points_sum, rank, world, group=None, device=None,
+                       allgather=None):
+    """InnerProductProof::create (src/inner_product_proof.rs:37-239) across `world` ranks.  Every rank passes the same full
+    vectors (only its cyclic slice is uploaded) and the same `challenge(L, R) -> u` transcript step; every rank returns the same
+    (L_vec, R_vec, a, b), bit-identical to the single-GPU result.  `stepper` is an Engine (or anything with ipa_begin /
+    ipa_round_LR / ipa_round_fold / ipa_export / ipa_finish).
+
+    Rounds while a rank holds >= 2 elements: local partial L, R (the <a_L, b_R> * Q term is linear too), all-gather of
+    (world x 2) points, host point-reduce, challenge, local fold.  When one element per rank is left the world elements are
+    gathered (with the scalar factors the engine still owes the generators as G_factors / H_factors of the continuation) and
+    every rank finishes the last lg(world) rounds redundantly.  `allgather(arr) -> (world, ...)` replaces the torch.distributed
+    exchange (tests drive several ranks as threads of one process)."""
+    if allgather is None:
+        def allgather(arr):
+            return allgather_words(arr, group, device)
+    n = len(a_vec)
+    if n == 0 or n & (n - 1):
+        raise ValueError("sharded_ipa_create: n must be a power of two")   # the reference asserts (:66)
+    if world & (world - 1):
+        raise ValueError("sharded_ipa_create: world size must be a power of two")
+    Ls, Rs = [], []
+
+    def finish_locally(Q, Gf, Hf, G, H, a, b):
+        stepper.ipa_begin(Q, Gf, Hf, G, H, a, b)
+        m = len(a)
+        while m > 1:
+            L, R = stepper.ipa_round_LR()
+            stepper.ipa_round_fold(challenge(L, R))
+            Ls.append(L)
+            Rs.append(R)
+            m //= 2
+        return stepper.ipa_finish()
+
+    if world == 1 or n < 2 * world:
+        ao, bo = finish_locally(Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec)
+        return np.array(Ls).reshape(-1, 8), np.array(Rs).reshape(-1, 8), ao, bo
+    sl = slice(rank, None, world)
+    stepper.ipa_begin(Q, np.asarray(G_factors)[sl], np.asarray(H_factors)[sl], np.asarray(G_vec)[sl], np.asarray(H_vec)[sl], np.asarray(a_vec)[sl],
+                      np.asarray(b_vec)[sl])
+    m = n // world
+    while m > 1:
+        Lp, Rp = stepper.ipa_round_LR()
+        parts = allgather(np.stack([Lp, Rp]))          # (world, 2, 8)
+        L, R = points_sum(curve, parts[:, 0]), points_sum(curve, parts[:, 1])
+        stepper.ipa_round_fold(challenge(L, R))
+        Ls.append(L)
+        Rs.append(R)
+        m //= 2
+    a1, b1, G1, H1, gG, gH = stepper.ipa_export(1)
+    allv = allgather(np.concatenate([a1[0], b1[0], G1[0], H1[0]]))   # (world, 24): global index = rank
+    ao, bo = finish_locally(Q, np.tile(gG, (world, 1)), np.tile(gH, (world, 1)), allv[:, 8:16], allv[:, 16:24], allv[:, 0:4], allv[:, 4:8])
+    return np.array(Ls).reshape(-1, 8), np.array(Rs).reshape(-1, 8), ao, bo
 
 
 def sharded_msm(curve, local_msm, points_sum, group=None, device=None):

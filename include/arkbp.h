@@ -84,6 +84,24 @@ int bp_ipa_create(bp_ctx* ctx, const uint64_t Q_xy[8], const uint64_t* G_factors
                   const uint64_t* H_xy, const uint64_t* a, const uint64_t* b, size_t n, bp_challenge_cb cb, void* user, uint64_t* L_out_xy,
                   uint64_t* R_out_xy, uint64_t a_out[4], uint64_t b_out[4]);
 
+/* The same computation cut at the Fiat-Shamir step, for hosts that keep the transcript on their side without a callback and
+ * for the index-cyclic multi-GPU partition (each rank holds the elements i = rank mod world of every vector; a round's L and R
+ * are then the sums of the ranks' partial points, see ark_bulletproofs_amd/parallel.py):
+ *   bp_ipa_begin       copies the instance to the GPU (the arguments of `create`, :37-46; n a power of two)
+ *   bp_ipa_round_LR    L, R of the current round (:78-131 / :166-213), affine ark layout; the host appends them (:132-133)
+ *   bp_ipa_round_fold  folds a, b, G, H with the challenge u (:137-155 / :214-224); u^-1 is derived by the engine
+ *   bp_ipa_finish      a[0], b[0] once the vectors have length 1 (:226-231)
+ *   bp_ipa_export      the current vectors between rounds (n_cur elements each) with the scalars the engine still owes the
+ *                      generator vectors: G_true[i] = gamma_G * G[i], H_true[i] = gamma_H * H[i] (uniform rounds fold
+ *                      G_R + u^-2 G_L and carry the common factor u instead of multiplying every point by it)
+ * One stepping instance per ctx; bp_ipa_begin restarts it. */
+int bp_ipa_begin(bp_ctx* ctx, const uint64_t Q_xy[8], const uint64_t* G_factors, const uint64_t* H_factors, const uint64_t* G_xy, const uint64_t* H_xy,
+                 const uint64_t* a, const uint64_t* b, size_t n);
+int bp_ipa_round_LR(bp_ctx* ctx, uint64_t L_xy[8], uint64_t R_xy[8]);
+int bp_ipa_round_fold(bp_ctx* ctx, const uint64_t u[4]);
+int bp_ipa_finish(bp_ctx* ctx, uint64_t a[4], uint64_t b[4]);
+int bp_ipa_export(bp_ctx* ctx, uint64_t* a, uint64_t* b, uint64_t* G_xy, uint64_t* H_xy, uint64_t gamma_G[4], uint64_t gamma_H[4], size_t* n_cur);
+
 /* ---- InnerProductProof::verify -------------------------------------------------------------------
  * Replaces `proof.verify(n, transcript, G_factors, H_factors, &P, &Q, &G, &H)` (src/inner_product_proof.rs:321-382).
  * The caller replays its transcript (`innerproduct_domain_sep`, `validate_and_append_point(L|R)`, `challenge_scalar(u)`,

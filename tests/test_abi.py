@@ -22,7 +22,7 @@ def lib():
 def test_header_symbols_are_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "arkbp.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(bp_[a-z0-9_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(bp_[A-Za-z0-9_]+)\s*\(", hdr)))
     assert declared, "no declarations parsed"
     L = lib.lib()
     for name in declared:

@@ -149,3 +149,122 @@ def test_sharded_batch_verify_gloo_world2():
         assert p.exitcode == 0
     for rank, out in res:
         assert out["ok"] == 0 and out["bad"] == -4, (rank, out)
+
+
+class _OracleIpaStepper:
+    """Stand-in for Engine's stepping interface (ipa_begin .. ipa_finish) built from the oracle's field / group primitives,
+    following src/inner_product_proof.rs:70-237 round by round; lets the index-cyclic partition run without a GPU."""
+
+    def __init__(self, O, cv):
+        self.O, self.cv, self.F = O, cv, O.fid(cv, True)
+
+    def _mul(self, x, y):
+        return self.O.fe_op("mul", self.F, x, y)
+
+    def ipa_begin(self, Q, Gf, Hf, G, H, a, b):
+        self.Q = np.array(Q, dtype=np.uint64)
+        self.Gf, self.Hf = [np.array(x, dtype=np.uint64) for x in Gf], [np.array(x, dtype=np.uint64) for x in Hf]
+        self.G, self.H = [np.array(x, dtype=np.uint64) for x in G], [np.array(x, dtype=np.uint64) for x in H]
+        self.a, self.b = [np.array(x, dtype=np.uint64) for x in a], [np.array(x, dtype=np.uint64) for x in b]
+        self.first = True
+
+    def _ip(self, x, y):
+        acc = self.O.fe_from_int(self.F, 0)
+        for p, q in zip(x, y):
+            acc = self.O.fe_op("add", self.F, acc, self._mul(p, q))
+        return acc
+
+    def ipa_round_LR(self):
+        O, cv, n = self.O, self.cv, len(self.a) // 2
+        one = O.fe_from_int(self.F, 1)
+        gf = self.Gf if self.first else [one] * (2 * n)
+        hf = self.Hf if self.first else [one] * (2 * n)
+        aL, aR, bL, bR = self.a[:n], self.a[n:], self.b[:n], self.b[n:]
+        cL, cR = self._ip(aL, bR), self._ip(aR, bL)
+        sL = [self._mul(aL[i], gf[n + i]) for i in range(n)] + [self._mul(bR[i], hf[i]) for i in range(n)] + [cL]
+        sR = [self._mul(aR[i], gf[i]) for i in range(n)] + [self._mul(bL[i], hf[n + i]) for i in range(n)] + [cR]
+        L = O.msm(cv, np.array(self.G[n:] + self.H[:n] + [self.Q]), np.array(sL))
+        R = O.msm(cv, np.array(self.G[:n] + self.H[n:] + [self.Q]), np.array(sR))
+        return L, R
+
+    def ipa_round_fold(self, u):
+        O, cv, n = self.O, self.cv, len(self.a) // 2
+        ui = O.fe_op("inv", self.F, u)
+        one = O.fe_from_int(self.F, 1)
+        gf = self.Gf if self.first else [one] * (2 * n)
+        hf = self.Hf if self.first else [one] * (2 * n)
+        add = lambda x, y: O.fe_op("add", self.F, x, y)   # noqa: E731
+        a2 = [add(self._mul(self.a[i], u), self._mul(ui, self.a[n + i])) for i in range(n)]
+        b2 = [add(self._mul(self.b[i], ui), self._mul(u, self.b[n + i])) for i in range(n)]
+        G2 = [O.point_add(cv, O.scalar_mul(cv, self.G[i], self._mul(ui, gf[i])), O.scalar_mul(cv, self.G[n + i], self._mul(u, gf[n + i]))) for i in range(n)]
+        H2 = [O.point_add(cv, O.scalar_mul(cv, self.H[i], self._mul(u, hf[i])), O.scalar_mul(cv, self.H[n + i], self._mul(ui, hf[n + i]))) for i in range(n)]
+        self.a, self.b, self.G, self.H, self.first = a2, b2, G2, H2, False
+
+    def ipa_export(self, n_max):
+        one = self.O.fe_from_int(self.F, 1)
+        if self.first:
+            raise RuntimeError("export before the first fold is not needed by the partition")
+        return np.array(self.a), np.array(self.b), np.array(self.G), np.array(self.H), one, one
+
+    def ipa_finish(self):
+        assert len(self.a) == 1
+        return self.a[0], self.b[0]
+
+
+def _ipa_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ark_bulletproofs_amd import engine as E
+        from ark_bulletproofs_amd import parallel as P
+        from oracle import pyoracle as O
+        from test_oracle_protocol import _ipa_instance
+
+        out = {}
+        for cv in (0, 1):
+            for n in (8, 2, 1):   # 8: two partitioned rounds + a gathered one; 2 and 1: fewer elements than 2 * world -> local
+                G, H, Q, a, b, Gf, Hf, _ = _ipa_instance(O, cv, n)
+                tr = O.Transcript(b"innerproducttest")
+                Lo, Ro, ao, bo = O.ipa_create(cv, tr.clone(), Q, Gf, Hf, G, H, a, b)
+                t1 = tr.clone()
+                t1.append_message(b"dom-sep", b"ipp v1")
+                t1.append_u64(b"n", n)
+
+                def ch(L, R, t1=t1, cv=cv):
+                    t1.append_point(cv, b"L", L)
+                    t1.append_point(cv, b"R", R)
+                    return t1.challenge_scalar(cv, b"u")
+
+                L, R, ag, bg = P.sharded_ipa_create(cv, _OracleIpaStepper(O, cv), Q, Gf, Hf, G, H, a, b, ch, E.host_points_sum, rank, world)
+                lg = max(n.bit_length() - 1, 0)
+                ok = (ag == ao).all() and (bg == bo).all() and L.shape == (lg, 8)
+                if lg:
+                    ok = ok and (L == Lo).all() and (R == Ro).all()
+                out["ipa%d_%d" % (cv, n)] = bool(ok)
+        dist.barrier()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ipa_create_gloo_world2():
+    """index-cyclic IPA over 2 gloo ranks: partial L/R all-gather + host point-reduce, gathered tail rounds"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ipa_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert all(out.values()), (rank, out)

@@ -141,3 +141,93 @@ def test_ipa_create_large_round_kernels_at_small_sizes(oracle, n):
         Lg, Rg, ag, bg = e.ipa_create(Q, Gf, Hf, G, H, a, b, _challenger(O, cv, tr))
         assert (Lg == Lo).all() and (Rg == Ro).all() and (ag == ao).all() and (bg == bo).all()
         e.close()
+
+
+def test_ipa_stepping_api_matches_callback_api(eng, oracle):
+    """bp_ipa_begin / round_LR / round_fold / finish = bp_ipa_create, and bp_ipa_export returns the vectors of the round
+    (with the pending generator factors) such that a fresh instance started from them finishes the same proof"""
+    O, cv = oracle, eng.curve
+    n = 32
+    G, H, Q, a, b, Gf, Hf, P = _ipa_instance(O, cv, n)
+    tr = O.Transcript(b"innerproducttest")
+    Lo, Ro, ao, bo = O.ipa_create(cv, tr.clone(), Q, Gf, Hf, G, H, a, b)
+    t1 = tr.clone()
+    t1.append_message(b"dom-sep", b"ipp v1")
+    t1.append_u64(b"n", n)
+    ch = _challenger(O, cv, t1)
+    eng.ipa_begin(Q, Gf, Hf, G, H, a, b)
+    Ls, Rs = [], []
+    for rnd in range(5):
+        if rnd == 3:   # export after three folds, restart from the exported state (factors = the pending gammas)
+            a4, b4, G4, H4, gG, gH = eng.ipa_export(n)
+            assert len(a4) == 4
+            eng.ipa_begin(Q, np.tile(gG, (4, 1)), np.tile(gH, (4, 1)), G4, H4, a4, b4)
+        L, R = eng.ipa_round_LR()
+        eng.ipa_round_fold(ch(L, R))
+        Ls.append(L)
+        Rs.append(R)
+    ag, bg = eng.ipa_finish()
+    assert (np.array(Ls) == Lo).all() and (np.array(Rs) == Ro).all() and (ag == ao).all() and (bg == bo).all()
+    import ark_bulletproofs_amd as A
+
+    with pytest.raises(A.ArkbpError):
+        eng.ipa_round_LR()            # finished: no instance
+    eng.ipa_begin(Q, Gf, Hf, G, H, a, b)
+    with pytest.raises(A.ArkbpError):
+        eng.ipa_round_fold(ao)        # fold before L, R
+    with pytest.raises(A.ArkbpError):
+        eng.ipa_finish()              # vectors still longer than 1
+
+
+@pytest.mark.parametrize("world,n", [(2, 16), (4, 64), (4, 4), (2, 2)])
+def test_ipa_index_cyclic_ranks_as_threads(oracle, world, n):
+    """IPA with every vector partitioned i mod world.  The ranks run as threads of this process (one Engine each on
+    the same GPU, an in-process all-gather); every rank must return the oracle's L_vec, R_vec, a, b."""
+    import threading
+
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+    from ark_bulletproofs_amd import parallel as P
+
+    O = oracle
+    for cv in (0, 1):
+        G, H, Q, a, b, Gf, Hf, Pt = _ipa_instance(O, cv, n)
+        u0 = O.fe_rand(O.fid(cv, True), bytes([9]) * 32, 1)[0]
+        Gf = Gf.copy()
+        Gf[n // 2:] = u0
+        tr = O.Transcript(b"innerproducttest")
+        Lo, Ro, ao, bo = O.ipa_create(cv, tr.clone(), Q, Gf, Hf, G, H, a, b)
+        bar = threading.Barrier(world)
+        slots = [None] * world
+        results = [None] * world
+        errors = []
+
+        def run(rank):
+            try:
+                eng = A.Engine(curve=cv)
+                t1 = tr.clone()
+                t1.append_message(b"dom-sep", b"ipp v1")
+                t1.append_u64(b"n", n)
+
+                def allgather(arr):
+                    slots[rank] = np.array(arr, copy=True)
+                    bar.wait()
+                    out = np.stack(slots)
+                    bar.wait()
+                    return out
+
+                results[rank] = P.sharded_ipa_create(cv, eng, Q, Gf, Hf, G, H, a, b, _challenger(O, cv, t1), E.host_points_sum, rank, world, allgather=allgather)
+                eng.close()
+            except Exception as e:   # release the others
+                errors.append(e)
+                bar.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        for r in range(world):
+            L, R, ag, bg = results[r]
+            assert (L == Lo).all() and (R == Ro).all() and (ag == ao).all() and (bg == bo).all()
