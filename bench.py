@@ -78,15 +78,19 @@ def synth_msm_inputs(eng, n, rank):
     return bases, sc
 
 
-def pmc_traffic(key, applicable):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_fetch_write_summary.json: FETCH_SIZE and
+def pmc_traffic(keys, applicable, fname="r01_pmc_fetch_write_summary.json", field="largest"):
+    """HBM bytes from the committed rocprofv3 PMC passes (profiles/<fname>, made by tools/pmc_summary.py from FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same workload).  FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950
-    tallies 128-B requests at 64 B for 16-B-per-lane loads); WRITE_SIZE is taken as is.  None when the run's shape differs."""
+    tallies 128-B requests at 64 B for 16-B-per-lane loads); WRITE_SIZE is taken as is.  field = "largest": the dispatch with the
+    largest grid; "all_launches": summed over the run.  keys: one kernel key or a list (summed).  None when the shape differs."""
     if not applicable:
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_summary.json")))[key]
-        return (2.0 * d["fetch_KiB_largest"] + d["write_KiB_largest"]) * 1024.0
+        d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        tot = 0.0
+        for k in ([keys] if isinstance(keys, str) else keys):
+            tot += (2.0 * d[k]["fetch_KiB_" + field] + d[k]["write_KiB_" + field]) * 1024.0
+        return tot
     except Exception:
         return None
 
@@ -139,8 +143,13 @@ def run_msm(args, rank, world, local):
         res["roofline"] = {"bound": "hbm", "kernel": "k_msm_accum", "achieved": n * 96 / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": n * 96 / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("msm/k_msm_accum<Secq>", n == 1 << 16 and args.curve == 0),
                            "avg_kernel_ms": acc_ms / acc_n,
-                           "msm_all_kernels_ms": tot_ms / max(tot_n, 1),
-                           "note": "integer-VALU-bound path: see DESIGN.md for the modmul/s model"}
+                           "msm_all_kernels_ms": tot_ms / max(tot_n, 1)}
+        W, c = E.msm_window_count(args.curve, n)
+        full_windows = [256, 255][args.curve] // c          # the remaining top window holds at most a few bits
+        madds = n * full_windows * (1.0 - 0.5 ** c)          # non-zero signed digits of uniform scalars
+        res["roofline"]["valu"] = {"unit": "G mixed adds/s", "achieved": madds / avg_s / 1e9, "peak": 12.9, "frac": madds / avg_s / 1e9 / 12.9,
+                                   "note": "the kernel is integer-VALU-bound: gathered mixed Jacobian+affine additions (11 modular products each) against "
+                                           "the measured add rate of this GPU (tools/ubench.hip, profiles/r01_ubench_radix29.txt)"}
     if rank == 0 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_msm(args, bases, sc)
     db.free()
@@ -253,10 +262,17 @@ def run_prove(args, rank, world, local):
         for (_, tm) in r:
             stages += np.array(tm)
     nproofs = args.batch * args.steps
-    fold_ms = sum(e.kernel_time(3)[0] for e in engs)
-    fold_n = sum(e.kernel_time(3)[1] for e in engs)
-    acc_ms = sum(e.kernel_time(0)[0] for e in engs)
-    msm_ms = sum(e.kernel_time(1)[0] for e in engs)
+    # kernel durations for the roofline: ONE more proof, alone on the GPU, after the timed region — HIP-event times taken while
+    # several streams share the GPU include the other streams' kernels
+    for e in engs:
+        e.reset_profiling()
+    iso = make_statements(200, 1)[0]
+    iso.precompute()
+    iso.prove(engs[0])
+    iso.free()
+    fold_ms, fold_n = engs[0].kernel_time(3)
+    acc_ms = engs[0].kernel_time(0)[0]
+    msm_ms = engs[0].kernel_time(1)[0]
     names = ["prove_total", "-", "transcript_rng", "uploads", "commit_msms", "flatten_constraints", "poly_kernels", "ipa"]
     res = {
         "metric": "r1cs_constraints_proved_per_sec", "value": N * world * nproofs / dt, "unit": "constraints/s", "n_gpus": world,
@@ -269,15 +285,27 @@ def run_prove(args, rank, world, local):
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
     if fold_n:
-        # dominant kernel: the IPA fold (k_ipa_fold_pts): per proof it reads 4*64 B and writes 2*64 B per folded pair of points
-        # plus 4*32 + 2*32 B of scalars, over sum_j n_j = N-1 pairs  => 576 B * (N-1)  (SURVEY.md §8d).  Event times of
-        # concurrent streams overlap each other, so the per-proof figure is an upper bound of the kernel's own duration.
-        per_proof_s = fold_ms / nproofs * 1e-3
-        res["roofline"] = {"bound": "hbm", "kernel": "k_ipa_fold_pts (+k_ipa_fold_ab), all rounds of one proof", "achieved": 576.0 * (N - 1) / per_proof_s / 1e9,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 576.0 * (N - 1) / per_proof_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                           "avg_kernel_ms": fold_ms / max(fold_n, 1), "fold_ms_per_proof": fold_ms / nproofs,
-                           "msm_kernels_ms_per_proof": msm_ms / nproofs, "msm_accum_ms_per_proof": acc_ms / nproofs,
-                           "note": "integer-VALU-bound path (2 x 256-bit scalar muls per folded point): see DESIGN.md"}
+        # dominant kernel group: the IPA G/H fold (k_ipa_fold_glv | k_ipa_fold_uniform, k_ipa_fold_finish, k_ipa_fold_ab).  Per proof it
+        # reads 4*64 B and writes 2*64 B per folded pair of points plus 4*32 + 2*32 B of scalars, over sum_j n_j = N-1 pairs
+        # => 576 B * (N-1)  (SURVEY.md §8d); the unit of `achieved`, `traffic` and the time is "all fold launches of one proof".
+        per_proof_s = fold_ms * 1e-3
+        # secondary, the bound that actually applies (integer VALU): modular products of the fold ladders against the measured
+        # product rate of this GPU (tools/ubench.hip, profiles/r01_ubench_radix29.txt: 169 G modmul/s).  Per output point:
+        # secq256k1 (GLV): 130 doublings x 7 + ~88 mixed adds x 11 + ~70 (endomorphism, shared inversion, conversions);
+        # zorro: 257 x 8 + ~87 x 11 + ~70.
+        per_lane = 1950.0 if args.curve == 0 else 3080.0
+        modmul = 2.0 * (N - 1) * per_lane
+        res["roofline"] = {"bound": "hbm", "kernel": "IPA G/H fold (k_ipa_fold_glv + k_ipa_fold_finish + k_ipa_fold_ab), all rounds of one proof",
+                           "achieved": 576.0 * (N - 1) / per_proof_s / 1e9,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 576.0 * (N - 1) / per_proof_s / 1e9 / HBM_PEAK_GBS,
+                           # HBM bytes of all fold launches of ONE proof (same unit as `achieved`), from the committed PMC passes of this shape
+                           "traffic": pmc_traffic(["prove2p20/k_ipa_fold_glv<Secq>", "prove2p20/k_ipa_fold_finish<Secq>", "prove2p20/k_ipa_fold_ab<Secq>"],
+                                                  args.logn == 20 and args.curve == 0, "r01_pmc_prove_2p20_summary.json", "all_launches"),
+                           "avg_kernel_ms": fold_ms / max(fold_n, 1), "fold_ms_per_proof": fold_ms,
+                           "msm_kernels_ms_per_proof": msm_ms, "msm_accum_ms_per_proof": acc_ms,
+                           "valu": {"unit": "G modmul/s", "achieved": modmul / per_proof_s / 1e9, "peak": 169.0, "frac": modmul / per_proof_s / 1e9 / 169.0,
+                                    "note": "the path is integer-VALU-bound (about 3.9 k modular products per 192 algorithmic bytes of a fold): this is the "
+                                            "fraction that measures the kernel; kernel times are from one proof run alone after the timed region"}}
     if rank == 0 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_prove(args)
     for e in engs[1:] + engs[:1]:
@@ -394,7 +422,7 @@ def cpu_baseline_msm(args, bases, sc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="prove", choices=["prove", "verify", "msm"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
