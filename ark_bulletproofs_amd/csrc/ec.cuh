@@ -172,7 +172,7 @@ template <class C> ARKBP_HD Aff jac_to_aff(const Jac& p) {
 
 // Tonelli-Shanks square root in Fq (p - 1 = 2^S * t; ark-ff's SqrtPrecomputation::TonelliShanks shape): false for a
 // non-residue.  Either root may come out; callers order (y, -y) canonically like ark-ec's get_ys_from_x_unchecked.
-template <class F> __device__ __noinline__ bool fe_sqrt(Fe& out, const Fe& a_in) {
+template <class F> ARKBP_DEV_NOINLINE bool fe_sqrt(Fe& out, const Fe& a_in) {
     const Fe a = fe_wred<F>(a_in);
     if (fe_is_zero_mod<F>(a)) { out = fe_zero<F>(); return true; }
     // w = a^((t-1)/2)
@@ -223,7 +223,7 @@ ARKBP_HD bool fe_canon_gt(const Fe& a, const Fe& b) {
 }
 
 // SW point from x and the sign flag of ark-serialize's compressed encoding (greatest = flag 0x80: y > -y)
-template <class C> __device__ __forceinline__ bool aff_from_x(Aff& out, const Fe& x_canon_rform, bool greatest) {
+template <class C> ARKBP_HD bool aff_from_x(Aff& out, const Fe& x_canon_rform, bool greatest) {
     typedef typename C::Fq F;
     Fe rhs = fe_mul<F>(fe_sqr<F>(x_canon_rform), x_canon_rform);
     if (!C::A_ZERO) rhs = fe_norm(fe_add(rhs, fe_times<(C::A_ZERO ? 1 : C::A_SMALL)>(x_canon_rform)));

@@ -25,8 +25,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define ARKBP_HD __host__ __device__ __forceinline__
+#define ARKBP_DEV_NOINLINE __device__ __noinline__
 #else
 #define ARKBP_HD inline
+#define ARKBP_DEV_NOINLINE inline
 #endif
 #include "arkbp_params.h"
 
