@@ -74,6 +74,10 @@ struct IpaState {
     const F4* rho_pw = nullptr;
     const u32* d_rho_pow = nullptr;
     bool lr_done = false;
+    // frozen-generator tail (ipa.cuh): from length n0 on, G and H stay as they are and per-element coefficients fold instead
+    bool allow_freeze = false, frozen = false;
+    size_t n0 = 0;
+    u32 *d_cG = nullptr, *d_cH = nullptr;
 };
 
 struct bp_ctx {
@@ -82,12 +86,13 @@ struct bp_ctx {
     bool profiling = false;
     size_t tune_fold_batch_min = 65536;   // BP_TUNE_FOLD_BATCH_MIN
     size_t tune_msm_bin_min = 64;         // BP_TUNE_MSM_BIN_MIN
+    size_t tune_ipa_freeze_len = 1024;    // BP_TUNE_IPA_FREEZE_LEN
     KTimer timers[BP_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // MSM workspaces
     DevBuf canon, hist, lvl_off, totals, cursor, entries, slots, bin_cur, boff, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
     // IPA workspaces (resident layouts)
-    DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q, ipa_jac, ipa_pref;
+    DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q, ipa_jac, ipa_pref, ipa_cG, ipa_cH;
     // generator tables (BulletproofGens party 0, PedersenGens), resident layout
     DevBuf d_G, d_H, d_pc;
     DevBuf pc_table;   // fixed-base window tables of B, B_blinding (pedersen.cuh), built on first use
@@ -480,7 +485,7 @@ template <class C> static int launch_uniform_fold(bp_ctx* ctx, u32* d_G, u32* d_
 static inline int ipa_lg2(size_t x) { int k = 0; while (((size_t)1 << k) < x) k++; return k; }
 
 template <class C> static int ipa_begin_dev(bp_ctx* ctx, IpaState& s, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, u32* d_G, u32* d_H, u32* d_a, u32* d_b,
-                                            size_t n, const F4* gf_halves, const F4* rho_pw, const u32* d_rho_pow) {
+                                            size_t n, const F4* gf_halves, const F4* rho_pw, const u32* d_rho_pow, bool allow_freeze = false) {
     typedef host::Fld<typename C::Fr> S;
     if (n == 0 || (n & (n - 1))) { g_err = "ipa_create: n must be a power of two (reference asserts, src/inner_product_proof.rs:66)"; return BP_E_ARG; }
     s = IpaState();
@@ -488,9 +493,11 @@ template <class C> static int ipa_begin_dev(bp_ctx* ctx, IpaState& s, const u32*
     s.gamma_G = S::one(); s.gamma_H = S::one();
     if (gf_halves) { s.have_gf = true; s.gf_halves[0] = gf_halves[0]; s.gf_halves[1] = gf_halves[1]; }
     if (rho_pw && d_rho_pow) { s.have_rho = true; s.rho_pw = rho_pw; s.d_rho_pow = d_rho_pow; }
-    BPCHK(ctx->ipa_sL.ensure((n + 1) * 32));
-    BPCHK(ctx->ipa_sR.ensure((n + 1) * 32));
-    BPCHK(ctx->ipa_part.ensure(((n / 2 + 255) / 256 + 1) * 64));
+    s.allow_freeze = allow_freeze;
+    const size_t fz = std::max<size_t>(ctx->tune_ipa_freeze_len, 2);
+    BPCHK(ctx->ipa_sL.ensure((std::max(n, 2 * fz) + 1) * 32));
+    BPCHK(ctx->ipa_sR.ensure((std::max(n, 2 * fz) + 1) * 32));
+    BPCHK(ctx->ipa_part.ensure(((std::max(n / 2, fz) + 255) / 256 + 1) * 64));
     return BP_OK;
 }
 // L, R of the current round (affine, ark layout): src/inner_product_proof.rs:78-131 (first round) / :166-213
@@ -503,6 +510,26 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
     const u32 gb = (u32)((n + 255) / 256);
     u32* sL = ctx->ipa_sL.as<u32>();
     u32* sR = ctx->ipa_sR.as<u32>();
+    if (s.frozen) {
+        const size_t n0 = s.n0;
+        const u32 gf = (u32)((n0 + 255) / 256);
+        {
+            ScopedK tk(ctx, BP_K_IPA_SCALARS);
+            hipLaunchKernelGGL(k_ipa_frozen_scalars<C>, dim3(gf), dim3(256), 0, st, s.d_a, s.d_b, s.d_cG, s.d_cH, (u32)n, (u32)n0, sL, sR, ctx->ipa_part.as<u32>());
+            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gf, sL + 2 * n0 * 8, sR + 2 * n0 * 8);
+        }
+        BaseSegs sg; memset(&sg, 0, sizeof sg);
+        sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n0; sg.start[2] = (u32)(2 * n0); sg.start[3] = (u32)(2 * n0 + 1);
+        sg.ptr[0] = s.d_G; sg.ptr[1] = s.d_H; sg.ptr[2] = s.d_Q;
+        J4 Lj, Rj;
+        BPCHK(msm_run<C>(ctx, sg, sL, 2 * n0 + 1, 0, Lj));
+        BPCHK(msm_run<C>(ctx, sg, sR, 2 * n0 + 1, 0, Rj));
+        A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
+        memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
+        memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
+        s.lr_done = true;
+        return BP_OK;
+    }
     {
         ScopedK tk(ctx, BP_K_IPA_SCALARS);
         hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, s.d_Gf, s.d_Hf, s.first ? 1 : 0, (u32)n, sL, sR, ctx->ipa_part.as<u32>(),
@@ -533,6 +560,15 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
     const bool first = s.first;
     F4 u; memcpy(u.v, uw, 32);
     F4 ui = S::inv(u);
+    if (s.frozen) {
+        ScopedK tk(ctx, BP_K_IPA_FOLD);
+        hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
+        hipLaunchKernelGGL(k_ipa_frozen_fold<C>, dim3((u32)((s.n0 + 255) / 256)), dim3(256), 0, st, s.d_cG, s.d_cH, (u32)n, (u32)s.n0, words_of<S>(u), words_of<S>(ui));
+        tk.stop();
+        HIPCHK(hipGetLastError());
+        s.round++; s.n = n; s.lr_done = false;
+        return BP_OK;
+    }
     {
         ScopedK tk(ctx, BP_K_IPA_FOLD);
         hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
@@ -580,6 +616,14 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
     s.round++;
     s.n = n;
     s.lr_done = false;
+    if (s.allow_freeze && n >= 2 && n <= ctx->tune_ipa_freeze_len) {   // the vectors just reached the freeze length: coefficients from here on
+        BPCHK(ctx->ipa_cG.ensure(n * 32)); BPCHK(ctx->ipa_cH.ensure(n * 32));
+        s.d_cG = ctx->ipa_cG.as<u32>(); s.d_cH = ctx->ipa_cH.as<u32>();
+        hipLaunchKernelGGL(k_ipa_freeze_init<C>, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, s.d_cG, s.d_cH, (u32)n, s.pending ? (s.h_geo ? 2 : 1) : 0,
+                           words_of<S>(s.gamma_G), words_of<S>(s.gamma_H), s.d_rho_pow);
+        HIPCHK(hipGetLastError());
+        s.frozen = true; s.n0 = n;
+    }
     return BP_OK;
 }
 // a[0], b[0] -> ark layout on the host (:226-231)
@@ -608,7 +652,7 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                                                         rho_pw[k] = rho^-(2^k), rho_pw[32+k] = rho^(2^k), k < 32 */,
                           const u32* d_rho_pow = nullptr /* device table of rho^(2^k), resident words */) {
     IpaState s;
-    BPCHK(ipa_begin_dev<C>(ctx, s, d_Q, d_Gf, d_Hf, d_G, d_H, d_a, d_b, n, gf_halves, rho_pw, d_rho_pow));
+    BPCHK(ipa_begin_dev<C>(ctx, s, d_Q, d_Gf, d_Hf, d_G, d_H, d_a, d_b, n, gf_halves, rho_pw, d_rho_pow, true));
     while (s.n != 1) {
         uint64_t Lw[8], Rw[8], uw[4];
         BPCHK(ipa_round_lr<C>(ctx, s, Lw, Rw));
@@ -823,7 +867,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     collect_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
-                      &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref,
+                      &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
                       &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables};
     c->templates.clear();
@@ -839,6 +883,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
     switch (knob) {
         case BP_TUNE_FOLD_BATCH_MIN: c->tune_fold_batch_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_BIN_MIN: c->tune_msm_bin_min = (size_t)value; return BP_OK;
+        case BP_TUNE_IPA_FREEZE_LEN: c->tune_ipa_freeze_len = (size_t)value; return BP_OK;
     }
     return BP_E_ARG;
 }

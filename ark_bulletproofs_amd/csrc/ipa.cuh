@@ -198,6 +198,72 @@ template <class C> __device__ __forceinline__ Jac shamir2(const Aff& P1, const A
     return acc;
 }
 
+// ---- frozen-generator tail rounds --------------------------------------------------------------------------------------
+// Below ~2^11 elements a fold launch is one lane's serial ladder (>= 1 ms) however few points it folds.  From length n0 on the
+// engine therefore stops folding G and H: it keeps the vectors G0, H0 of that moment and a coefficient per element,
+//   G_true[j] = sum over t = j (mod len) of cG[t] * G0[t]      (len = current vector length; same for H),
+// so a fold is cG[t] *= (t mod len < len/2 ? u^-1 : u) (and the mirror for cH), and L, R of a round are MSMs over ALL of G0, H0
+// (2*n0 + 1 terms, every base used by exactly one of L, R; the other gets a zero scalar, which costs nothing in the bucket sort).
+// a and b fold as before.  (src/inner_product_proof.rs:166-224 computes the same L, R, a', b'; G', H' are never output.)
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_freeze_init(u32* __restrict__ cG, u32* __restrict__ cH, u32 n0, int pending, Words8 gGw, Words8 gHw, const u32* __restrict__ rho_pow) {
+    typedef typename C::Fr F;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n0) return;
+    Fe g = fe_one<F>(), h = fe_one<F>();
+    if (pending) {
+        g = fe_load_ark<F>(gGw.w);
+        h = fe_load_ark<F>(gHw.w);
+        if (pending == 2) h = fe_mul<F>(h, pow_table<F>(rho_pow, t));
+    }
+    store_fe_dev<F>(cG + (size_t)t * 8, g);
+    store_fe_dev<F>(cH + (size_t)t * 8, h);
+}
+// n = half of the current length.  sL / sR: (2*n0 + 1) x 8 words (canonical); partials as in k_ipa_scalars.
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_frozen_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ cG, const u32* __restrict__ cH, u32 n, u32 n0,
+                     u32* __restrict__ sL, u32* __restrict__ sR, u32* __restrict__ partials) {
+    typedef typename C::Fr F;
+    __shared__ u32 sh[9 * 256];
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fe pl = fe_zero<F>(), pr = fe_zero<F>();
+    if (t < n) {   // <a_L, b_R>, <a_R, b_L>
+        pl = fe_mul<F>(load_fe_dev<F>(a + (size_t)t * 8), load_fe_dev<F>(b + (size_t)(n + t) * 8));
+        pr = fe_mul<F>(load_fe_dev<F>(a + (size_t)(n + t) * 8), load_fe_dev<F>(b + (size_t)t * 8));
+    }
+    if (t < n0) {
+        const u32 r = t & (2 * n - 1);
+        const bool lo = r < n;
+        const u32 j = lo ? r : r - n;
+        const Fe g = load_fe_dev<F>(cG + (size_t)t * 8), h = load_fe_dev<F>(cH + (size_t)t * 8);
+        const Fe zero = fe_zero<F>();
+        // G part: L pairs a_L[j] with G_R[j] (r >= n), R pairs a_R[j] with G_L[j] (r < n)
+        const Fe xg = fe_mul<F>(load_fe_dev<F>(a + (size_t)(lo ? n + j : j) * 8), g);
+        store_fe_canon<F>(sL + (size_t)t * 8, lo ? zero : xg);
+        store_fe_canon<F>(sR + (size_t)t * 8, lo ? xg : zero);
+        // H part: L pairs b_R[j] with H_L[j] (r < n), R pairs b_L[j] with H_R[j] (r >= n)
+        const Fe xh = fe_mul<F>(load_fe_dev<F>(b + (size_t)(lo ? n + j : j) * 8), h);
+        store_fe_canon<F>(sL + (size_t)(n0 + t) * 8, lo ? xh : zero);
+        store_fe_canon<F>(sR + (size_t)(n0 + t) * 8, lo ? zero : xh);
+    }
+    pl = block_sum_fe<F>(fe_wred<F>(pl), sh);
+    pr = block_sum_fe<F>(fe_wred<F>(pr), sh);
+    if (threadIdx.x == 0) {
+        store_fe_dev<F>(partials + (size_t)blockIdx.x * 16, pl);
+        store_fe_dev<F>(partials + (size_t)blockIdx.x * 16 + 8, pr);
+    }
+}
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_frozen_fold(u32* __restrict__ cG, u32* __restrict__ cH, u32 n, u32 n0, Words8 uw, Words8 uiw) {
+    typedef typename C::Fr F;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n0) return;
+    const Fe u = fe_load_ark<F>(uw.w), ui = fe_load_ark<F>(uiw.w);
+    const bool lo = (t & (2 * n - 1)) < n;
+    store_fe_dev<F>(cG + (size_t)t * 8, fe_mul<F>(load_fe_dev<F>(cG + (size_t)t * 8), lo ? ui : u));
+    store_fe_dev<F>(cH + (size_t)t * 8, fe_mul<F>(load_fe_dev<F>(cH + (size_t)t * 8), lo ? u : ui));
+}
+
 // Fold epilogue.  jac_ws == nullptr: the lane inverts its own Z (one a^(p-2) ladder, ~450 products) and writes the affine point.
 // Large rounds pass a workspace instead: lane t leaves its Jacobian result there and k_ipa_fold_finish converts the whole
 // round with ONE inversion per m points (Montgomery's trick along a strided run of points per lane).

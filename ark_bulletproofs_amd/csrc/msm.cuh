@@ -430,10 +430,22 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
         end = min(beg + (1u << chl), off0[b + 1]);
     }
     Jac acc = jac_inf<C>();
-    for (u32 e = beg; e < end; e++) {
-        const u32 ent = entries[e];
+    if (beg < end) {
+        // the gather of entry e+1 (entry word, then a 64-byte base somewhere in a table far larger than L2) is issued before the
+        // mixed add of entry e, so its latency hides behind ~3 k VALU instructions instead of stalling the lane
+        u32 ent = entries[beg];
         Aff p = load_aff_dev(seg_base_ptr(segs, ent >> 1));
-        acc = jac_madd<C>(acc, aff_cneg_lazy<C>(p, ent & 1));
+        for (u32 e = beg; e < end; e++) {
+            u32 ent_n = ent;
+            Aff p_n = p;
+            if (e + 1 < end) {
+                ent_n = entries[e + 1];
+                p_n = load_aff_dev(seg_base_ptr(segs, ent_n >> 1));
+            }
+            acc = jac_madd<C>(acc, aff_cneg_lazy<C>(p, ent & 1));
+            ent = ent_n;
+            p = p_n;
+        }
     }
     store_jac_ws<C>(out + (size_t)j * 24, acc);
 }

@@ -213,9 +213,12 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
 
 /* Size thresholds at which the engine switches kernels (results never depend on them; the tests lower them to drive the
  * large-input paths with small inputs).  FOLD_BATCH_MIN: output points per IPA fold round from which the affine conversion
- * shares inversions (default 65536); MSM_BIN_MIN: terms from which the MSM uses the two-level sort (default 64). */
+ * shares inversions (default 65536); MSM_BIN_MIN: terms from which the MSM uses the two-level sort (default 64);
+ * IPA_FREEZE_LEN: vector length from which bp_ipa_create / the prover stop folding G and H and fold per-element coefficients
+ * over the frozen vectors instead (default 1024; 0 or 1 = never). */
 #define BP_TUNE_FOLD_BATCH_MIN 0
 #define BP_TUNE_MSM_BIN_MIN 1
+#define BP_TUNE_IPA_FREEZE_LEN 2
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 
 /* ---- unit-test hooks: one field / group operation per element on the GPU -------------------------- */

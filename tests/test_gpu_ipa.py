@@ -119,10 +119,12 @@ def test_ipa_verify_on_gpu(eng, oracle, n):
     assert eng.ipa_verify(n, Gf, Hf, P, Q, G, H, Lg, Rg, np.array(chg).reshape(-1, 4), ag, bg) == 0
 
 
+@pytest.mark.parametrize("freeze", [0, 4, 16])
 @pytest.mark.parametrize("n", [4, 64, 256])
-def test_ipa_create_large_round_kernels_at_small_sizes(oracle, n):
+def test_ipa_create_large_round_kernels_at_small_sizes(oracle, n, freeze):
     """the kernels large rounds switch to (shared-inversion fold epilogue k_ipa_fold_finish, two-level MSM sort) driven with
-    small inputs through bp_ctx_set_tuning: same bytes as the oracle"""
+    small inputs through bp_ctx_set_tuning, with the generator folds kept to the end (freeze = 0) or replaced by coefficient
+    folds over frozen vectors from length 4 / 16 on: same bytes as the oracle"""
     import ark_bulletproofs_amd as A
 
     O = oracle
@@ -130,6 +132,7 @@ def test_ipa_create_large_round_kernels_at_small_sizes(oracle, n):
         e = A.Engine(curve=cv)
         e.set_tuning(0, 1)
         e.set_tuning(1, 1)
+        e.set_tuning(2, freeze)
         G, H, Q, a, b, Gf, Hf, P = _ipa_instance(O, cv, n)
         H = H.copy()
         H[0] = 0                      # an identity among the folded points (Z = 0 inside the shared inversion)

@@ -46,9 +46,11 @@ def test_prove_matches_oracle_bytes(eng, oracle, sc, prm):
     assert O.r1cs_verify(cv, sc, prm, 128, got.proof, got.commitments, got.publics) == rc_ref
 
 
+@pytest.mark.parametrize("freeze", [0, 8])
 @pytest.mark.parametrize("sc,prm", [(0, [24]), (1, [32, 77]), (3, [100, 0]), (4, [3, 8, 0])])
-def test_prove_large_round_kernels_at_small_sizes(oracle, sc, prm):
-    """prover with the large-input kernels forced (shared-inversion fold epilogue, two-level MSM sort): same proof bytes"""
+def test_prove_large_round_kernels_at_small_sizes(oracle, sc, prm, freeze):
+    """prover with the large-input kernels forced (shared-inversion fold epilogue, two-level MSM sort), generator folds to the
+    end (freeze = 0) or coefficient folds over frozen vectors from length 8 on: same proof bytes"""
     import ark_bulletproofs_amd as A
 
     for cv in (0, 1):
@@ -56,6 +58,7 @@ def test_prove_large_round_kernels_at_small_sizes(oracle, sc, prm):
         e.gens_derive(128)
         e.set_tuning(0, 1)
         e.set_tuning(1, 1)
+        e.set_tuning(2, freeze)
         ref = oracle.r1cs_prove(cv, sc, prm, SEED, 128, m_cap=128)
         got = e.prove_scenario(sc, prm, SEED, m_cap=128)
         assert got.proof == ref.proof and (got.commitments == ref.commitments).all()
