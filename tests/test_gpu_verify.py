@@ -147,3 +147,53 @@ def test_proof_sharded_batch_points_sum_to_identity(eng, oracle):
     rc_full, _, pt_full = eng.batch_verify(inst, seed, want_point=True)
     assert rc_full == E_VERIFICATION
     assert (E.host_points_sum(cv, np.stack(pts)) == pt_full).all()
+
+
+def test_batch_pipeline_many_blocks(eng, oracle):
+    """batches longer than one pipeline block (512 instances): mixed templates inside and across blocks, two-phase (shuffle)
+    statements in between, a failing instance in a late block, the first error in instance order when a format error and a
+    verification error are both present, and the check point of the whole batch against two half batches (alpha_skip)."""
+    from ark_bulletproofs_amd import engine as E
+
+    O, cv = oracle, eng.curve
+    kinds = [(3, [20, 0]), (1, [8, 200]), (4, [2, 8, 0]), (0, [5]), (3, [20, 0]), (3, [9, 0])]
+    distinct = []
+    for i, (sc, prm) in enumerate(kinds):
+        pr = eng.prove_scenario(sc, prm, bytes([60 + i]) * 32, m_cap=32)
+        distinct.append((sc, prm, pr.proof, pr.commitments, pr.publics))
+    n = 1300
+    inst = [distinct[(i * 7 + i // 100) % len(distinct)] for i in range(n)]
+    seed = bytes([9]) * 32
+    rc, _, pt = eng.batch_verify(inst, seed, want_point=True)
+    assert rc == OK and not pt.any()
+    # the oracle agrees on a prefix it can do in seconds (same alphas by position)
+    assert O.batch_verify(cv, inst[:40], 128, seed) == 0
+    # one verification failure in the third block
+    sc, prm, proof, cm, pb = inst[1100]
+    bad = bytearray(proof)
+    bad[11 * 33 + 40] ^= 2   # t_x_blinding
+    bad_inst = list(inst)
+    bad_inst[1100] = (sc, prm, bytes(bad), cm, pb)
+    rc, _, pt_bad = eng.batch_verify(bad_inst, seed, want_point=True)
+    assert rc == E_VERIFICATION and pt_bad.any()
+    # halves with alpha_skip reproduce the whole batch's check point
+    lo = 650
+    _, _, p0 = eng.batch_verify(bad_inst[:lo], seed, alpha_skip=0, want_point=True)
+    _, _, p1 = eng.batch_verify(bad_inst[lo:], seed, alpha_skip=lo, want_point=True)
+    assert (E.host_points_sum(cv, np.stack([p0, p1])) == pt_bad).all()
+    # a malformed encoding late in the batch is a FormatError even though an earlier instance fails verification
+    # (the reference decodes every proof before batch_verify runs)
+    sc, prm, proof, cm, pb = inst[1200]
+    worse = bytearray(proof)
+    worse[32] |= 0x20        # reserved flag bit of the first compressed point
+    bad_inst[1200] = (sc, prm, bytes(worse), cm, pb)
+    rc, _ = eng.batch_verify(bad_inst, seed)
+    assert rc == E_FORMAT
+    # wrong commitment (statement mismatch) in the first block, everything else fine
+    sc, prm, proof, cm, pb = inst[3]
+    other = inst[4][3] if len(inst[4][3]) == len(cm) else cm[::-1].copy()
+    mism = list(inst)
+    mism[3] = (sc, prm, proof, other if (other != cm).any() else cm[::-1].copy(), pb)
+    if (np.asarray(mism[3][3]) != np.asarray(cm)).any():
+        rc, _ = eng.batch_verify(mism, seed)
+        assert rc == E_VERIFICATION
