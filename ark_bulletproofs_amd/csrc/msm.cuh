@@ -310,9 +310,16 @@ k_msm_bin_sort(u32* __restrict__ ent, const u32* __restrict__ bin_cur, u32* __re
 // ceil(cnt / CH^k) chunks.  totals[k] = lvl_off[k][B]; totals[NLMAX] = max bucket population.
 // Three launches: per-tile sums, one-workgroup scan of the tile sums, per-tile exclusive scan.
 static constexpr int MSM_NLMAX = MSM_MAXLVL + 1;
+// population of a bucket at level k+1 given level k (level 0 = entries, level k >= 1 = partial sums).  "Special" buckets (the
+// narrow top window: a handful of buckets holding ~n/2 entries each) go through level 1 like everyone else and are then
+// finished by k_msm_reduce_special in ONE launch, instead of stretching the generic tree by lg16(n) levels for their sake.
+__device__ __forceinline__ u32 msm_next_level(u32 v, int k, int chl, bool special) {
+    if (special && k >= 1) return v ? 1u : 0u;
+    return (v + (1u << chl) - 1) >> chl;
+}
 static constexpr int MSM_SCAN_TILE = 2048;  // buckets per workgroup (256 lanes x 8)
 
-__global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ hist, u32* __restrict__ tile_sums, u32 B, int nl, int chl) {
+__global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ hist, u32* __restrict__ tile_sums, u32 B, int nl, int chl, u32 b_gen) {
     __shared__ u32 sh[MSM_NLMAX + 1][4];
     const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
     u32 sum[MSM_NLMAX + 1];
@@ -320,8 +327,8 @@ __global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ 
     for (u32 j = 0; j < 8; j++) {
         const u32 b = base + j;
         u32 v = b < B ? hist[b] : 0;
-        sum[MSM_NLMAX] = max(sum[MSM_NLMAX], v);
-        for (int k = 0; k < nl; k++) { sum[k] += v; v = (v + (1u << chl) - 1) >> chl; }
+        if (b < b_gen) sum[MSM_NLMAX] = max(sum[MSM_NLMAX], v);   // the depth of the generic tree; special buckets have their own kernel
+        for (int k = 0; k < nl; k++) { sum[k] += v; v = msm_next_level(v, k, chl, b >= b_gen); }
     }
     for (int k = 0; k <= MSM_NLMAX; k++) {
         u32 v = sum[k];
@@ -348,7 +355,7 @@ __global__ void __launch_bounds__(64) k_msm_scan_top(u32* __restrict__ tile_sums
     totals[k] = run;
     if (k < MSM_NLMAX) lvl_off[(size_t)k * (B + 1) + B] = run;
 }
-__global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl, int chl) {
+__global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl, int chl, u32 b_gen) {
     __shared__ u32 sh[MSM_NLMAX][4];
     const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -359,7 +366,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ 
         const u32 b = base + j;
         u32 v = b < B ? hist[b] : 0;
         cnt[j] = v;
-        for (int k = 0; k < nl; k++) { sum[k] += v; v = (v + (1u << chl) - 1) >> chl; }
+        for (int k = 0; k < nl; k++) { sum[k] += v; v = msm_next_level(v, k, chl, b >= b_gen); }
     }
     u32 excl[MSM_NLMAX];
     for (int k = 0; k < nl; k++) {   // inclusive scan across the wave, then exclusive
@@ -378,7 +385,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ 
         const u32 b = base + j;
         if (b >= B) break;
         u32 v = cnt[j];
-        for (int k = 0; k < nl; k++) { lvl_off[(size_t)k * (B + 1) + b] = excl[k]; excl[k] += v; v = (v + (1u << chl) - 1) >> chl; }
+        for (int k = 0; k < nl; k++) { lvl_off[(size_t)k * (B + 1) + b] = excl[k]; excl[k] += v; v = msm_next_level(v, k, chl, b >= b_gen); }
     }
 }
 
@@ -453,15 +460,49 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
 // 5. level k >= 2: lane j sums chunk j of level k-1 partials
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_reduce(const u32* __restrict__ in, const u32* __restrict__ off_prev, const u32* __restrict__ off_cur, u32* __restrict__ out, u32 B,
-             u32 nchunks, int chl) {
+             u32 nchunks, int chl, u32 skip_from /* buckets >= skip_from are left to k_msm_reduce_special at this level */) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nchunks) return;
     const u32 b = find_bucket(off_cur, B, j);
+    if (b >= skip_from) return;
     const u32 beg = off_prev[b] + ((j - off_cur[b]) << chl);
     const u32 end = min(beg + (1u << chl), off_prev[b + 1]);
     Jac acc = load_jac_ws(in + (size_t)beg * 24);
     for (u32 e = beg + 1; e < end; e++) acc = jac_add<C>(acc, load_jac_ws(in + (size_t)e * 24));
     store_jac_ws<C>(out + (size_t)j * 24, acc);
+}
+
+// sum of the 256 lanes' points, valid in lane 0.  LDS tree: limbs stored limb-major (27 rows of 256 words) so lanes hit distinct banks
+template <class C> __device__ __forceinline__ Jac block_sum_jac(Jac acc, u32* __restrict__ sh /* 256 * 27 words */) {
+    const u32 tid = threadIdx.x;
+    for (u32 stride = 128; stride >= 1; stride >>= 1) {
+        if (tid >= stride && tid < 2 * stride) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) { sh[i * 256 + tid] = acc.X.l[i]; sh[(9 + i) * 256 + tid] = acc.Y.l[i]; sh[(18 + i) * 256 + tid] = acc.Z.l[i]; }
+        }
+        __syncthreads();
+        if (tid < stride) {
+            Jac o;
+#pragma unroll
+            for (int i = 0; i < 9; i++) { o.X.l[i] = sh[i * 256 + tid + stride]; o.Y.l[i] = sh[(9 + i) * 256 + tid + stride]; o.Z.l[i] = sh[(18 + i) * 256 + tid + stride]; }
+            acc = jac_add<C>(acc, o);
+        }
+        __syncthreads();
+    }
+    return acc;
+}
+// 5b. special buckets: one workgroup sums ALL level-1 partials of its bucket into the bucket's single level-2 slot
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_reduce_special(const u32* __restrict__ in, const u32* __restrict__ off1, const u32* __restrict__ off2, u32* __restrict__ out, u32 b_gen, u32 B) {
+    __shared__ u32 sh[256 * 27];
+    const u32 b = b_gen + blockIdx.x;
+    if (b >= B) return;
+    const u32 beg = off1[b], end = off1[b + 1];
+    if (beg == end) return;   // (uniform for the workgroup)
+    Jac acc = jac_inf<C>();
+    for (u32 e = beg + threadIdx.x; e < end; e += 256) acc = jac_add<C>(acc, load_jac_ws(in + (size_t)e * 24));
+    acc = block_sum_jac<C>(acc, sh);
+    if (threadIdx.x == 0) store_jac_ws<C>(out + (size_t)off2[b] * 24, acc);
 }
 
 // 6. marginal sums: block (w, k) adds every bucket of window w whose value v = idx+1 has bit k set.
@@ -481,21 +522,7 @@ k_msm_marginals(const u32* __restrict__ sums, const u32* __restrict__ off, u32* 
         if (off[b + 1] == o) continue;  // empty bucket
         acc = jac_add<C>(acc, load_jac_ws(sums + (size_t)o * 24));
     }
-    // LDS tree: limbs stored limb-major (27 rows of 256 words) so lanes hit distinct banks
-    for (u32 stride = 128; stride >= 1; stride >>= 1) {
-        if (tid >= stride && tid < 2 * stride) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) { sh[i * 256 + tid] = acc.X.l[i]; sh[(9 + i) * 256 + tid] = acc.Y.l[i]; sh[(18 + i) * 256 + tid] = acc.Z.l[i]; }
-        }
-        __syncthreads();
-        if (tid < stride) {
-            Jac o;
-#pragma unroll
-            for (int i = 0; i < 9; i++) { o.X.l[i] = sh[i * 256 + tid + stride]; o.Y.l[i] = sh[(9 + i) * 256 + tid + stride]; o.Z.l[i] = sh[(18 + i) * 256 + tid + stride]; }
-            acc = jac_add<C>(acc, o);
-        }
-        __syncthreads();
-    }
+    acc = block_sum_jac<C>(acc, sh);
     if (tid == 0) {
         u32* o = T_out + ((size_t)w * pl.c + k) * 24;
         u32 wd[8];
