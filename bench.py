@@ -78,7 +78,7 @@ def synth_msm_inputs(eng, n, rank):
     return bases, sc
 
 
-def pmc_traffic(keys, applicable, fname="r01_pmc_fetch_write_summary.json", field="largest"):
+def pmc_traffic(keys, applicable, fname, field="largest"):
     """HBM bytes from the committed rocprofv3 PMC passes (profiles/<fname>, made by tools/pmc_summary.py from FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same workload).  FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950
     tallies 128-B requests at 64 B for 16-B-per-lane loads); WRITE_SIZE is taken as is.  field = "largest": the dispatch with the
@@ -141,7 +141,7 @@ def run_msm(args, rank, world, local):
     if acc_n:
         avg_s = acc_ms / acc_n * 1e-3
         res["roofline"] = {"bound": "hbm", "kernel": "k_msm_accum", "achieved": n * 96 / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": n * 96 / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("msm/k_msm_accum<Secq>", n == 1 << 16 and args.curve == 0),
+                           "frac": n * 96 / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("msm/k_msm_accum<Secq>", n == 1 << 16 and args.curve == 0, "r01_pmc_msm_2p16_summary.json"),
                            "avg_kernel_ms": acc_ms / acc_n,
                            "msm_all_kernels_ms": tot_ms / max(tot_n, 1)}
         W, c = E.msm_window_count(args.curve, n)
@@ -381,7 +381,8 @@ def run_verify(args, rank, world, local):
         # block per proof and the shared CSC, and writes chunk partials
         nproofs_per_launch = inst.n * args.steps / max(vs_n, 1)  # the batch goes through in blocks of 512 proofs, one k_vfy_batch launch each
         res["roofline"] = {"bound": "hbm", "kernel": "k_vfy_batch (one launch per block of 512 proofs)", "achieved": 160.0 * N * nproofs_per_launch / avg_s / 1e9,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * N * nproofs_per_launch / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * N * nproofs_per_launch / avg_s / 1e9 / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic("verify4096/k_vfy_batch<Secq>", args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512, "r01_pmc_verify_4096_summary.json"),
                            "avg_kernel_ms": vs_ms / vs_n, "algorithmic_bytes_per_verify": per_proof_bytes}
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import pyoracle as O
