@@ -106,6 +106,11 @@ struct bp_ctx {
     size_t h_vstage_cap[2] = {0, 0};
     hipEvent_t vstage_ev[2] = {nullptr, nullptr};
     std::map<std::string, std::shared_ptr<void>> templates;
+    // window-sharded multi-GPU mode (bp_ctx_set_window_shard): every MSM of this ctx accumulates only this rank's Pippenger
+    // windows and the ranks' partial points are summed through the host's collective
+    int shard_rank = 0, shard_world = 1;
+    bp_point_reduce_cb shard_cb = nullptr;
+    void* shard_user = nullptr;
     IpaState ipa_step;         // bp_ipa_begin .. bp_ipa_finish
     bool ipa_step_active = false;
     u32* h_totals = nullptr;  // pinned
@@ -163,8 +168,24 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (n >= (1u << 31)) { g_err = "msm: n too large"; return BP_E_ARG; }
     hipStream_t st = ctx->stream;
     MsmPlan pl = msm_plan(n, C::Fr::BITS);
+    const bool sharded = w_hi < 0 && ctx->shard_world > 1;
+    if (sharded) {   // contiguous block partition of the windows (the same rule as parallel.shard_range)
+        const int base = pl.W / ctx->shard_world, rem = pl.W % ctx->shard_world, r = ctx->shard_rank;
+        w_lo = r * base + std::min(r, rem);
+        w_hi = w_lo + base + (r < rem ? 1 : 0);
+    }
+    auto finish_sharded = [&](J4& part) -> int {   // partial point -> sum over the ranks (one 64-byte exchange)
+        if (!sharded) return BP_OK;
+        A4 a = G::to_aff(part);
+        uint64_t xy[8]; memcpy(xy, a.x.v, 32); memcpy(xy + 4, a.y.v, 32);
+        const int rc = ctx->shard_cb(ctx->shard_user, xy);
+        if (rc) { g_err = "msm: the point-reduce callback failed"; return rc < 0 ? rc : BP_E_ARG; }
+        memcpy(a.x.v, xy, 32); memcpy(a.y.v, xy + 4, 32);
+        part = G::from_aff(a);
+        return BP_OK;
+    };
     if (w_hi >= 0) { pl.w_lo = std::max(0, w_lo); pl.w_hi = std::min(pl.W, w_hi); }
-    if (pl.w_lo >= pl.w_hi) return BP_OK;  // this rank owns no window: the identity
+    if (pl.w_lo >= pl.w_hi) return finish_sharded(result);  // this rank owns no window: the identity
     constexpr int NL = MSM_NLMAX;
     int nl = 2;  // levels 0..nl-1 can be needed: 16^(nl-1) >= n
     { u64 cap = MSM_CH; while (cap < n && nl < NL) { cap *= MSM_CH; nl++; } }   // sized for the smaller fan-in
@@ -285,7 +306,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     }
     const u32* tot = ctx->h_totals;
     const u32 maxcnt = tot[NL];
-    if (tot[0] == 0) { total.stop(); return BP_OK; }  // every digit zero: the identity
+    if (tot[0] == 0) { total.stop(); return finish_sharded(result); }  // every digit zero: the identity
     // levels: 1 = chunks of entries; k >= 2 = chunks of level k-1 partials; stop when a bucket holds <= 1
     int K = 1;
     { u64 cap = (u64)1 << chl; while (cap < maxcnt) { cap <<= chl; K++; } }
@@ -324,7 +345,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     }
     (void)sizeof(F);
     result = acc;
-    return BP_OK;
+    return finish_sharded(result);
 }
 
 template <class C> static void aff_out(uint64_t out[8], const A4& a) { memcpy(out, a.x.v, 32); memcpy(out + 4, a.y.v, 32); }
@@ -885,6 +906,11 @@ void bp_ctx_destroy(bp_ctx* c) {
     for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); }
     (void)hipStreamDestroy(c->stream);
     delete c;
+}
+int bp_ctx_set_window_shard(bp_ctx* c, int rank, int world, bp_point_reduce_cb cb, void* user) {
+    if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !cb)) return BP_E_ARG;
+    c->shard_rank = rank; c->shard_world = world; c->shard_cb = cb; c->shard_user = user;
+    return BP_OK;
 }
 int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
     if (!c) return BP_E_ARG;

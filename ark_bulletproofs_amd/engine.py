@@ -85,6 +85,27 @@ class Engine:
         check(lib().bp_msm_dev(self.ctx, d_bases.ptr, d_scalars.ptr, C.c_size_t(n), int(canonical), ptr(out)), "bp_msm_dev")
         return out
 
+    def set_window_shard(self, rank, world, reduce_fn=None):
+        """window-sharded mode (bp_ctx_set_window_shard): reduce_fn(xy: (8,) u64) -> (8,) u64 = sum of all ranks' partial points"""
+        if world <= 1:
+            check(lib().bp_ctx_set_window_shard(self.ctx, 0, 1, None, None), "bp_ctx_set_window_shard")
+            self._shard_cb = None
+            return
+        errs = self._shard_errors = []
+
+        def cb(_user, xy):
+            try:
+                out = reduce_fn(np.array(xy[:8], dtype=np.uint64))
+                for i in range(8):
+                    xy[i] = int(out[i])
+                return 0
+            except Exception as e:  # never unwind through C
+                errs.append(e)
+                return 1
+
+        self._shard_cb = _POINT_REDUCE_CB(cb)   # keep the thunk alive as long as the mode is on
+        check(lib().bp_ctx_set_window_shard(self.ctx, int(rank), int(world), self._shard_cb, None), "bp_ctx_set_window_shard")
+
     def set_tuning(self, knob, value):
         """knob: 0 fold-batch minimum lanes, 1 MSM two-level-sort minimum terms (include/arkbp.h BP_TUNE_*)"""
         check(lib().bp_ctx_set_tuning(self.ctx, int(knob), C.c_uint64(int(value))), "bp_ctx_set_tuning")
@@ -117,6 +138,7 @@ class Engine:
 
 
 # ---- InnerProductProof::create ---------------------------------------------------------------------
+_POINT_REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64))
 _CHALLENGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
 

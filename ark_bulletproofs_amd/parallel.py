@@ -7,6 +7,7 @@ local (world-1)-add point-reduce).  SURVEY.md §8(e).
   window_sharded_msm    window sharding: every rank holds all terms and owns a range of Pippenger windows
   sharded_batch_verify  whole proofs per rank; by linearity the sum of the per-rank mega-check points is the
                         reference's single MSM (src/r1cs/verifier.rs:685)
+  enable_window_sharding  whole prover / verifier calls with every inner MSM window-sharded (bp_ctx_set_window_shard)
   sharded_ipa_create    InnerProductProof::create with every vector partitioned index-cyclically (rank r owns the elements
                         i = r mod world): element i and its fold partner n/2 + i live on the same rank, so all folds are
                         local; a round exchanges one pair of partial (L, R) points per rank
@@ -119,6 +120,20 @@ def window_sharded_msm(curve, n, local_msm_windows, window_count, points_sum, ra
     lo, hi = shard_range(W, rank, world)
     part = local_msm_windows(lo, hi) if hi > lo else np.zeros(8, dtype=np.uint64)
     return points_sum(curve, allgather_points(part, group, device))
+
+
+def enable_window_sharding(engine, curve, points_sum, rank, world, group=None, device=None, allgather=None):
+    """north_star's partition for one large proof: every rank runs the same prover / verifier call on the same statement, every
+    MSM inside accumulates only this rank's Pippenger windows, and the partial points are summed here (all-gather of one
+    64-byte point per rank + host point-reduce).  All ranks end with the identical proof."""
+    if allgather is None:
+        def allgather(arr):
+            return allgather_words(arr, group, device)
+
+    def reduce_fn(xy):
+        return points_sum(curve, allgather(xy).reshape(-1, 8))
+
+    engine.set_window_shard(rank, world, reduce_fn if world > 1 else None)
 
 
 def sharded_batch_verify(curve, instances, local_batch_verify, points_sum, rank, world, group=None, device=None):

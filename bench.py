@@ -173,19 +173,27 @@ def run_prove(args, rank, world, local):
     from ark_bulletproofs_amd import engine as E
 
     N = 1 << args.logn
-    P = max(1, args.inflight)
+    P = 1 if (args.shard == "windows" and world > 1) else max(1, args.inflight)
     engs = [A.Engine(curve=args.curve, device=local) for _ in range(P)]
     t0 = time.perf_counter()
     engs[0].gens_derive(N)
     t_gens = time.perf_counter() - t0
     for e in engs[1:]:
         e.share_gens_from(engs[0])
+    window_sharded = args.shard == "windows" and world > 1
+    if window_sharded:
+        # north_star / cfg5 partition: all ranks prove the SAME statements; every MSM inside prove() accumulates the rank's Pippenger
+        # windows and the partial points are summed over RCCL (strong scaling of one proof at a time: one proof in flight, because
+        # the ranks must issue their per-MSM collectives in the same order)
+        from ark_bulletproofs_amd import parallel as PP
+
+        PP.enable_window_sharding(engs[0], args.curve, E.host_points_sum, rank, world, device="cuda")
 
     def make_statements(tag, count):
         out = [None] * count
 
         def mk(k):
-            out[k] = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], bytes([3 + tag, 1 + (k & 0xFF), k >> 8] + [3] * 29))
+            out[k] = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], bytes([3 + tag, 1 + (k & 0xFF), k >> 8] + [3] * 29))   # same on every rank
 
         for lo in range(0, count, 16):   # at most 16 statements under construction at once
             th = [threading.Thread(target=mk, args=(k,)) for k in range(lo, min(lo + 16, count))]
@@ -275,12 +283,12 @@ def run_prove(args, rank, world, local):
     msm_ms = engs[0].kernel_time(1)[0]
     names = ["prove_total", "-", "transcript_rng", "uploads", "commit_msms", "flatten_constraints", "poly_kernels", "ipa"]
     res = {
-        "metric": "r1cs_constraints_proved_per_sec", "value": N * world * nproofs / dt, "unit": "constraints/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": "r1cs_constraints_proved_per_sec", "value": N * (1 if window_sharded else world) * nproofs / dt, "unit": "constraints/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if window_sharded else "weak",
         "vs_baseline": None, "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
         "config": {"workload": "cfg3: 2^%d-constraint R1CS prove (square-chain circuit, m=1, q=2N+1), %s, a step = %d independent proofs per GPU (%d GPU streams, %d host threads for the TranscriptRng stage)"
                                % (args.logn, ["secq256k1", "zorro"][args.curve], args.batch, P, args.host_threads),
-                   "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": "replicas x%d" % world,
+                   "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
                    "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
@@ -434,7 +442,8 @@ def main():
     ap.add_argument("--host-threads", type=int, default=3, help="host threads running the TranscriptRng head of prove()")
     ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--terms", type=int, default=1 << 16)
-    ap.add_argument("--shard", default="terms", choices=["terms", "windows"], help="multi-GPU MSM sharding (msm workload)")
+    ap.add_argument("--shard", default="terms", choices=["terms", "windows"],
+                    help="multi-GPU partition: msm workload: terms | Pippenger windows; prove workload: replicas (default) | windows = every rank proves the same statements with window-sharded MSMs")
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

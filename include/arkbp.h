@@ -72,6 +72,16 @@ int bp_msm_window_count(int curve, size_t n, int* windows, int* window_bits);
 int bp_msm_dev_windows(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int scalars_canonical, int w_lo, int w_hi,
                        uint64_t out_xy[8]);
 
+/* Window-sharded mode for whole computations (north_star: "large proofs shard Pippenger windows across the GPUs of one node with
+ * a final point-reduce"): after bp_ctx_set_window_shard(ctx, rank, world, cb, user) EVERY MSM this ctx runs (bp_msm*, the L/R
+ * MSMs of bp_ipa_create, the commitment MSMs of the prover, the verifier's mega-check) accumulates only the windows of `rank`
+ * and then calls cb(user, xy): the callback must replace the partial point in xy by the sum of all ranks' partials
+ * (all-gather over RCCL + bp_host_points_sum) and return 0.  All ranks run the same call sequence on the same inputs and obtain
+ * identical results (same proof bytes).  world = 1 switches the mode off.  Calls with an explicit window range
+ * (bp_msm_dev_windows) are not affected. */
+typedef int (*bp_point_reduce_cb)(void* user, uint64_t xy[8]);
+int bp_ctx_set_window_shard(bp_ctx* ctx, int rank, int world, bp_point_reduce_cb cb, void* user);
+
 /* ---- InnerProductProof::create -------------------------------------------------------------------
  * Replaces `InnerProductProof::create(transcript, &Q, &G_factors, &H_factors, G_vec, H_vec, a_vec, b_vec)`
  * (src/inner_product_proof.rs:37-239).  Host buffers of length n (a power of two, as the reference

@@ -268,3 +268,57 @@ def test_sharded_ipa_create_gloo_world2():
         assert p.exitcode == 0
     for rank, out in res:
         assert all(out.values()), (rank, out)
+
+
+def _wshard_worker(rank, world, port, q):
+    """enable_window_sharding over gloo: the reduce function installed on the engine must turn each rank's partial point into
+    the same full sum on every rank (the engine side — windows per rank inside every MSM — is covered by the GPU tests)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ark_bulletproofs_amd import engine as E
+        from ark_bulletproofs_amd import parallel as P
+        from oracle import pyoracle as O
+
+        class FakeEngine:
+            def set_window_shard(self, r, w, fn=None):
+                self.args = (r, w, fn)
+
+        out = {}
+        for cv in (0, 1):
+            G, _ = O.bp_gens(cv, world + 1)
+            fe = FakeEngine()
+            P.enable_window_sharding(fe, cv, E.host_points_sum, rank, world)
+            r, w, fn = fe.args
+            full = np.zeros(8, dtype=np.uint64)
+            for i in range(world):
+                full = O.point_add(cv, full, G[i])
+            out["sum%d" % cv] = bool(r == rank and w == world and (fn(G[rank]) == full).all())
+            out["identity%d" % cv] = bool((fn(np.zeros(8, dtype=np.uint64) if rank else G[0]) == G[0]).all())
+            P.enable_window_sharding(fe, cv, E.host_points_sum, 0, 1)
+            out["off%d" % cv] = fe.args[1] == 1 and fe.args[2] is None
+        dist.barrier()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_enable_window_sharding_gloo_world2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wshard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert all(out.values()), (rank, out)

@@ -123,3 +123,61 @@ def test_batched_precompute_x8(eng, oracle):
         assert proof == O.r1cs_prove(cv, sc, prm, bytes([70 + i]) * 32, 128, m_cap=8).proof
     proof, _ = odd.prove(eng)
     assert proof == O.r1cs_prove(cv, 1, [16, 5], bytes([90]) * 32, 128).proof
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_window_sharded_prover_ranks_as_threads(oracle, world):
+    """north_star / cfg5 partition: every rank runs the same prove() and verify(), each MSM inside accumulates only the rank's
+    Pippenger windows, partial points are summed through the host collective (here: an in-process all-gather between threads,
+    one Engine per rank on the same GPU).  Every rank must emit the oracle's proof bytes and accept it."""
+    import threading
+
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+    from ark_bulletproofs_amd import parallel as P
+
+    for cv in (0, 1):
+        cases = [(0, [7]), (3, [100, 0]), (4, [3, 8, 0])]
+        refs = [oracle.r1cs_prove(cv, sc, prm, SEED, 128, m_cap=128) for sc, prm in cases]
+        bar = threading.Barrier(world)
+        slots = [None] * world
+        out = [None] * world
+        errors = []
+
+        def run(rank):
+            try:
+                e = A.Engine(curve=cv)
+                e.gens_derive(128)
+
+                def allgather(arr):
+                    slots[rank] = np.array(arr, copy=True)
+                    bar.wait()
+                    res = np.stack(slots)
+                    bar.wait()
+                    return res
+
+                P.enable_window_sharding(e, cv, E.host_points_sum, rank, world, allgather=allgather)
+                got = []
+                for (sc, prm), ref in zip(cases, refs):
+                    pr = e.prove_scenario(sc, prm, SEED, m_cap=128)
+                    rc = e.verify_scenario(sc, prm, pr.proof, pr.commitments, pr.publics)
+                    bad = bytearray(pr.proof)
+                    bad[-1] ^= 1
+                    rc_bad = e.verify_scenario(sc, prm, bytes(bad), pr.commitments, pr.publics)
+                    got.append((pr.proof, rc, rc_bad))
+                out[rank] = got
+                P.enable_window_sharding(e, cv, E.host_points_sum, 0, 1)
+                e.close()
+            except Exception as ex:
+                errors.append(ex)
+                bar.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        for r in range(world):
+            for (proof, rc, rc_bad), ref in zip(out[r], refs):
+                assert proof == ref.proof and rc == 0 and rc_bad in (-4, -6)
