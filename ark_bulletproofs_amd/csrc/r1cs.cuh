@@ -179,19 +179,25 @@ static constexpr u32 VFY_PB_SCALARS = VFY_PB_WORDS / 8;
 //   s[i]       = allinv * prod_{bit j of i set} u_sq[k-1-j]      = s_lo[lo] * s_hi[hi]     (inner_product_proof.rs:302-311 in closed form)
 //   s[N-1-i]   = allinv * prod_{bit j of i clear} u_sq[k-1-j]    = r_lo[lo] * r_hi[hi]
 //   y^-i                                                          = y_lo[lo] * y_hi[hi]
-// so the batch kernel pays 3 products per (proof, i) instead of ~k + k/2.  Layout per proof: 3 x (2^LOB + 2^HIB) resident scalars,
-// [s_lo | s_hi | r_lo | r_hi | y_lo | y_hi].  grid (ceil(2^max(LOB,HIB) / 256), P).
+//   z^e  (e = q + 1 <= Q)                                         = z_lo[e & 255] * z_hi[e >> 8]
+// so the batch kernel pays one product for each of them instead of ~k, ~k/2 and ~lg(Q)/2.  Layout per proof (resident scalars):
+// [s_lo | s_hi | r_lo | r_hi | y_lo | y_hi | z_lo (256) | z_hi (nzhi)], stride 3 * (2^LOB + 2^HIB) + 256 + nzhi.
+// grid (ceil(max(2^LOB, 2^HIB, 256, nzhi) / 256), P).
 template <class C> __global__ void __launch_bounds__(256)
-k_vfy_tables(const u32* __restrict__ params, u32 P, u32 k, u32 LOB, u32* __restrict__ tables) {
+k_vfy_tables(const u32* __restrict__ params, u32 P, u32 k, u32 LOB, u32 nzhi, u32* __restrict__ tables) {
     typedef typename C::Fr F;
     const u32 tIdx = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
     if (p >= P) return;
     const u32 HIB = k - LOB, nlo = 1u << LOB, nhi = 1u << HIB;
     const u32* pb = params + (size_t)p * VFY_PB_WORDS;
+    const u32* ztab = pb;
     const u32* ytab = pb + 256;
     const u32* cst = pb + 512;
     const u32* usq = pb + 576;
-    u32* T = tables + (size_t)p * 3 * (nlo + nhi) * 8;
+    u32* T = tables + (size_t)p * (3 * (nlo + nhi) + 256 + nzhi) * 8;
+    u32* Z = T + (size_t)3 * (nlo + nhi) * 8;
+    if (tIdx < 256) store_fe_dev<F>(Z + (size_t)tIdx * 8, pow_table<F>(ztab, tIdx));
+    if (tIdx < nzhi) store_fe_dev<F>(Z + (size_t)(256 + tIdx) * 8, pow_table<F>(ztab, tIdx << 8));
     if (tIdx < nlo) {
         Fe s = load_fe_dev<F>(cst), r = s;
         for (u32 j = 0; j < LOB; j++) {
@@ -217,7 +223,7 @@ k_vfy_tables(const u32* __restrict__ params, u32 P, u32 k, u32 LOB, u32* __restr
 // grid (ceil(N/256), nchunks).  g_part/h_part: [nchunks][N] resident words; d_part: [nchunks * gridDim.x] resident words.
 template <class C> __global__ void __launch_bounds__(256)
 k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chunk, u32 n, u32 N, u32 k, u32* __restrict__ g_part,
-            u32* __restrict__ h_part, u32* __restrict__ d_part, const u32* __restrict__ tables, u32 LOB) {
+            u32* __restrict__ h_part, u32* __restrict__ d_part, const u32* __restrict__ tables, u32 LOB, u32 nzhi) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,21 +240,21 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chu
             const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
             const Fe alpha = load_fe_dev<F>(cst + 40);
             const u32 nlo = 1u << LOB, nhi = 1u << (k - LOB), lo = i & (nlo - 1u), hi = i >> LOB;
-            const u32* T = tables + (size_t)p * 3 * (nlo + nhi) * 8;
+            const u32* T = tables + (size_t)p * (3 * (nlo + nhi) + 256 + nzhi) * 8;
+            const u32* Z = T + (size_t)3 * (nlo + nhi) * 8;   // z^e = Z[e & 255] * Z[256 + (e >> 8)]
             const Fe s_i = fe_mul<F>(load_fe_dev<F>(T + (size_t)lo * 8), load_fe_dev<F>(T + (size_t)(nlo + hi) * 8));
             const Fe s_rev = fe_mul<F>(load_fe_dev<F>(T + (size_t)(nlo + nhi + lo) * 8), load_fe_dev<F>(T + (size_t)(nlo + nhi + nlo + hi) * 8));
             const Fe yni = fe_mul<F>(load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + lo) * 8), load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * 8));
             (void)allinv; (void)usq; (void)ytab;
             Fe g, h;
             if (i < n) {
-                // columns i of W_L, W_R, W_O in one pass over their entries sorted by constraint index: z^(q+1) is carried
-                // from entry to entry (a product with z^(dq), dq small) instead of being rebuilt from the power table
+                // columns i of W_L, W_R, W_O in one pass over their entries sorted by constraint index (equal indices reuse the
+                // power); z^(q+1) is one product of two entries of the proof's split table
                 Fe wL = fe_zero<F>(), wR = fe_zero<F>(), wO = fe_zero<F>(), zp = fe_one<F>();
-                u32 cur = 0;
+                u32 cur = 0;   // exponent zp holds (0 = none yet; q + 1 >= 1 always)
                 for (u32 e = t.m_off[i], e1 = t.m_off[i + 1]; e < e1; e++) {
                     const u32 ent = t.m_ent[e], q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
-                    if (cur == 0) zp = pow_table<F>(ztab, q1);
-                    else if (q1 != cur) zp = fe_mul<F>(zp, pow_table<F>(ztab, q1 - cur));
+                    if (q1 != cur) zp = fe_mul<F>(load_fe_dev<F>(Z + (size_t)(q1 & 255u) * 8), load_fe_dev<F>(Z + (size_t)(256u + (q1 >> 8)) * 8));
                     cur = q1;
                     const Fe term = fe_mul<F>(zp, load_fe_dev<F>(t.coefs + (size_t)t.m_c[e] * 8));
                     if (vec == 0) wL = fe_addr<F>(wL, term); else if (vec == 1) wR = fe_addr<F>(wR, term); else wO = fe_addr<F>(wO, term);
@@ -274,7 +280,7 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chu
             // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms
             Fe wcp = fe_zero<F>();
             for (u32 e = i; e < t.n_const; e += N)
-                wcp = fe_addr<F>(wcp, fe_mul<F>(pow_table<F>(ztab, t.const_q[e] + 1), load_fe_dev<F>(t.coefs + (size_t)t.const_c[e] * 8)));
+                wcp = fe_addr<F>(wcp, fe_mul<F>(pow_table<F>(ztab, t.const_q[e] + 1), load_fe_dev<F>(t.coefs + (size_t)t.const_c[e] * 8)));   // (a handful of terms per circuit)
             if (t.n_const > i) ad = fe_addr<F>(ad, fe_neg<F, 4>(fe_mul<F>(load_fe_dev<F>(cst + 48), wcp)));
         }
         store_fe_dev<F>(g_part + ((size_t)chunk * N + i) * 8, ag);
