@@ -101,10 +101,14 @@ struct bp_ctx {
     // R1CS prover / verifier vectors (resident scalar layout)
     DevBuf r_aL, r_aR, r_aO, r_sL, r_sR, r_wL, r_wR, r_wO, r_msmsc, r_ypow, r_part, r_small, r_g, r_h, r_chal, r_tail;
     // batch verification: per-proof parameter blocks, chunk partials; cached circuit templates (VTemplate<C>)
-    DevBuf v_params, v_gpart, v_hpart, v_alpha, v_tables;
+    DevBuf v_params, v_gpart, v_hpart, v_alpha, v_tables, v_dec;
     void* h_vstage[2] = {nullptr, nullptr};   // pinned staging halves of the batch-verify pipeline
     size_t h_vstage_cap[2] = {0, 0};
     hipEvent_t vstage_ev[2] = {nullptr, nullptr};
+    void* h_dec = nullptr;                    // pinned: x words, points, flags, ok of a batch's compressed points
+    size_t h_dec_cap = 0;
+    hipStream_t aux_stream = nullptr;         // point decompression runs beside the main stream
+    hipEvent_t dec_ev[2] = {nullptr, nullptr};
     std::map<std::string, std::shared_ptr<void>> templates;
     // window-sharded multi-GPU mode (bp_ctx_set_window_shard): every MSM of this ctx accumulates only this rank's Pippenger
     // windows and the ranks' partial points are summed through the host's collective
@@ -898,12 +902,14 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
-                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables};
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec};
     c->templates.clear();
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
-    for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); }
+    for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); if (c->dec_ev[i]) (void)hipEventDestroy(c->dec_ev[i]); }
+    if (c->h_dec) (void)hipHostFree(c->h_dec);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -189,6 +189,27 @@ def test_batch_pipeline_many_blocks(eng, oracle):
     bad_inst[1200] = (sc, prm, bytes(worse), cm, pb)
     rc, _ = eng.batch_verify(bad_inst, seed)
     assert rc == E_FORMAT
+    # an x coordinate that is not on the curve, in the last block (its square root is taken by the decode that runs one block
+    # ahead of the replay): FormatError as well, also when only an earlier instance fails verification
+    sc, prm, proof, cm, pb = inst[1290]
+    off_curve = None
+    for delta in range(1, 40):
+        cand = bytearray(proof)
+        cand[0] = (cand[0] + delta) & 0xFF
+        _, ok = eng.debug_decompress(bytes(cand[:33]))
+        if not ok[0]:
+            off_curve = bytes(cand)
+            break
+    assert off_curve is not None
+    late = list(inst)
+    late[1290] = (sc, prm, off_curve, cm, pb)
+    rc, _ = eng.batch_verify(late, seed)
+    assert rc == E_FORMAT
+    sc1, prm1, proof1, cm1, pb1 = inst[1100]
+    late[20] = bad_inst[1100] if inst[20][0] == sc1 and inst[20][1] == prm1 else late[20]
+    late[1100] = (sc1, prm1, bytes(bad), cm1, pb1)
+    rc, _ = eng.batch_verify(late, seed)
+    assert rc == E_FORMAT
     # wrong commitment (statement mismatch) in the first block, everything else fine
     sc, prm, proof, cm, pb = inst[3]
     other = inst[4][3] if len(inst[4][3]) == len(cm) else cm[::-1].copy()
