@@ -82,9 +82,17 @@ template <class P> struct Fld {
     static inline F4 from_u64(u64 x) { F4 a = {{x, 0, 0, 0}}, r2 = {{P::R2_64[0], P::R2_64[1], P::R2_64[2], P::R2_64[3]}}; return mul(a, r2); }
     static inline F4 from_canon(const u64 c[4]) { F4 a; memcpy(a.v, c, 32); F4 r2 = {{P::R2_64[0], P::R2_64[1], P::R2_64[2], P::R2_64[3]}}; return mul(a, r2); }
     static inline void to_canon(u64 c[4], const F4& a) { F4 o = {{1, 0, 0, 0}}; F4 r = mul(a, o); memcpy(c, r.v, 32); }
-    static inline F4 pow(const F4& a, const u64 e[4]) {
+    static inline F4 pow(const F4& a, const u64 e[4]) {   // fixed 4-bit windows: 256 squarings + <= 64 products + 14 for the table
+        F4 tab[16];
+        tab[0] = one(); tab[1] = a;
+        for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
         F4 r = one();
-        for (int i = 255; i >= 0; i--) { r = sqr(r); if ((e[i >> 6] >> (i & 63)) & 1) r = mul(r, a); }
+        bool started = false;
+        for (int i = 63; i >= 0; i--) {
+            const unsigned d = (unsigned)(e[i >> 4] >> ((i & 15) * 4)) & 15u;
+            if (started) { r = sqr(r); r = sqr(r); r = sqr(r); r = sqr(r); }
+            if (d) { r = started ? mul(r, tab[d]) : tab[d]; started = true; }
+        }
         return r;
     }
     static inline F4 inv(const F4& a) { return pow(a, P::PM2_64); }  // 0 -> 0
