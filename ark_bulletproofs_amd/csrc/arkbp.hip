@@ -193,7 +193,8 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     constexpr int NL = MSM_NLMAX;
     int nl = 2;  // levels 0..nl-1 can be needed: 16^(nl-1) >= n
     { u64 cap = MSM_CH; while (cap < n && nl < NL) { cap *= MSM_CH; nl++; } }   // sized for the smaller fan-in
-    if (nl < 3) nl = 3;   // the special buckets of the top window always meet in level 2
+    if (nl < 4) nl = 4;   // the special buckets of the top window meet one level after spl <= 2
+    const int spl = n > ((size_t)1 << 17) ? 2 : 1;   // hot bucket ~ n/2 entries: keep the special kernel at <= 32 partials per lane
     const size_t Bp1 = (size_t)pl.B + 1;
     const u32 ntiles = (pl.B + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
     BPCHK(ctx->canon.ensure(n * 32));
@@ -264,7 +265,8 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     u32 b_gen = pl.B;   // buckets below b_gen go through the generic reduction tree; the rest (narrow top window) are special
     auto front_end = [&](bool bins) -> int {
         chl = bins ? MSM_CHL_BINNED : MSM_CHL;
-        b_gen = (bins && bp.top_nb) ? (u32)bp.wb * (u32)pl.NB : pl.B;
+        static const bool no_special = getenv("ARKBP_MSM_NOSPECIAL") != nullptr;
+        b_gen = (bins && bp.top_nb && bp.top_nb <= 16 && !no_special) ? (u32)bp.wb * (u32)pl.NB : pl.B;   // few, huge buckets only: a wider top window fits the generic tree
         const size_t nslots = make_slots(sp, bins ? (int)bp.wb : 0, bins ? (size_t)bp.wb * bp.NBIN * bp.cap : 0);
         if (nslots >= ((size_t)1 << 32)) { g_err = "msm: slot array too large"; return BP_E_ARG; }
         BPCHK(ctx->slots.ensure(nslots * 4));
@@ -287,9 +289,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
             hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont, sp,
                                ctx->slots.as<u32>(), d_over);
         }
-        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl, chl, b_gen);
+        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl, chl, b_gen, spl);
         hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
-        hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl, chl, b_gen);
+        hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl, chl, b_gen, spl);
         HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
@@ -315,7 +317,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     int K = 1;
     { u64 cap = (u64)1 << chl; while (cap < maxcnt) { cap <<= chl; K++; } }
     const bool special = b_gen < pl.B;
-    if (special && K < 2) K = 2;   // the special buckets' partials meet in level 2
+    if (special && K < spl + 1) K = spl + 1;   // the special buckets' partials meet in level spl + 1
     if (K >= nl) { g_err = "msm: bucket population exceeds the reduction depth"; return BP_E_ARG; }
     BPCHK(ctx->lvA.ensure((size_t)tot[1] * 96));
     if (K >= 2) BPCHK(ctx->lvB.ensure((size_t)tot[2] * 96));
@@ -328,9 +330,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     u32* nxt = ctx->lvB.as<u32>();
     for (int k = 2; k <= K; k++) {
         hipLaunchKernelGGL(k_msm_reduce<C>, dim3((tot[k] + TB - 1) / TB), dim3(TB), 0, st, cur, lvl + Bp1 * (k - 1), lvl + Bp1 * k, nxt, pl.B, tot[k], chl,
-                           (k == 2 && special) ? b_gen : pl.B);
-        if (k == 2 && special)
-            hipLaunchKernelGGL(k_msm_reduce_special<C>, dim3(bp.top_nb), dim3(256), 0, st, cur, lvl + Bp1, lvl + Bp1 * 2, nxt, b_gen, pl.B);
+                           (k == spl + 1 && special) ? b_gen : pl.B);
+        if (k == spl + 1 && special)
+            hipLaunchKernelGGL(k_msm_reduce_special<C>, dim3(bp.top_nb), dim3(256), 0, st, cur, lvl + Bp1 * spl, lvl + Bp1 * (spl + 1), nxt, b_gen, pl.B);
         u32* t = cur; cur = nxt; nxt = t;
     }
     hipLaunchKernelGGL(k_msm_marginals<C>, dim3(pl.W, pl.c), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl);

@@ -311,15 +311,16 @@ k_msm_bin_sort(u32* __restrict__ ent, const u32* __restrict__ bin_cur, u32* __re
 // Three launches: per-tile sums, one-workgroup scan of the tile sums, per-tile exclusive scan.
 static constexpr int MSM_NLMAX = MSM_MAXLVL + 1;
 // population of a bucket at level k+1 given level k (level 0 = entries, level k >= 1 = partial sums).  "Special" buckets (the
-// narrow top window: a handful of buckets holding ~n/2 entries each) go through level 1 like everyone else and are then
-// finished by k_msm_reduce_special in ONE launch, instead of stretching the generic tree by lg16(n) levels for their sake.
-__device__ __forceinline__ u32 msm_next_level(u32 v, int k, int chl, bool special) {
-    if (special && k >= 1) return v ? 1u : 0u;
+// narrow top window: a handful of buckets holding ~n/2 entries each) go through the first spl levels like everyone else (fully
+// parallel over chunks) and are then finished by k_msm_reduce_special in ONE launch (one workgroup per bucket, <= 32 partials
+// per lane), instead of stretching the generic tree by lg16(n) levels for their sake.
+__device__ __forceinline__ u32 msm_next_level(u32 v, int k, int chl, bool special, int spl /* level whose partials the special kernel sums */) {
+    if (special && k >= spl) return v ? 1u : 0u;
     return (v + (1u << chl) - 1) >> chl;
 }
 static constexpr int MSM_SCAN_TILE = 2048;  // buckets per workgroup (256 lanes x 8)
 
-__global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ hist, u32* __restrict__ tile_sums, u32 B, int nl, int chl, u32 b_gen) {
+__global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ hist, u32* __restrict__ tile_sums, u32 B, int nl, int chl, u32 b_gen, int spl) {
     __shared__ u32 sh[MSM_NLMAX + 1][4];
     const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
     u32 sum[MSM_NLMAX + 1];
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32* __restrict__ 
         const u32 b = base + j;
         u32 v = b < B ? hist[b] : 0;
         if (b < b_gen) sum[MSM_NLMAX] = max(sum[MSM_NLMAX], v);   // the depth of the generic tree; special buckets have their own kernel
-        for (int k = 0; k < nl; k++) { sum[k] += v; v = msm_next_level(v, k, chl, b >= b_gen); }
+        for (int k = 0; k < nl; k++) { sum[k] += v; v = msm_next_level(v, k, chl, b >= b_gen, spl); }
     }
     for (int k = 0; k <= MSM_NLMAX; k++) {
         u32 v = sum[k];
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(64) k_msm_scan_top(u32* __restrict__ tile_sums
     totals[k] = run;
     if (k < MSM_NLMAX) lvl_off[(size_t)k * (B + 1) + B] = run;
 }
-__global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl, int chl, u32 b_gen) {
+__global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl, int chl, u32 b_gen, int spl) {
     __shared__ u32 sh[MSM_NLMAX][4];
     const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ 
         const u32 b = base + j;
         u32 v = b < B ? hist[b] : 0;
         cnt[j] = v;
-        for (int k = 0; k < nl; k++) { sum[k] += v; v = msm_next_level(v, k, chl, b >= b_gen); }
+        for (int k = 0; k < nl; k++) { sum[k] += v; v = msm_next_level(v, k, chl, b >= b_gen, spl); }
     }
     u32 excl[MSM_NLMAX];
     for (int k = 0; k < nl; k++) {   // inclusive scan across the wave, then exclusive
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ 
         const u32 b = base + j;
         if (b >= B) break;
         u32 v = cnt[j];
-        for (int k = 0; k < nl; k++) { lvl_off[(size_t)k * (B + 1) + b] = excl[k]; excl[k] += v; v = msm_next_level(v, k, chl, b >= b_gen); }
+        for (int k = 0; k < nl; k++) { lvl_off[(size_t)k * (B + 1) + b] = excl[k]; excl[k] += v; v = msm_next_level(v, k, chl, b >= b_gen, spl); }
     }
 }
 
@@ -491,7 +492,7 @@ template <class C> __device__ __forceinline__ Jac block_sum_jac(Jac acc, u32* __
     }
     return acc;
 }
-// 5b. special buckets: one workgroup sums ALL level-1 partials of its bucket into the bucket's single level-2 slot
+// 5b. special buckets: one workgroup sums ALL level-spl partials of its bucket into the bucket's single slot of the next level
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_reduce_special(const u32* __restrict__ in, const u32* __restrict__ off1, const u32* __restrict__ off2, u32* __restrict__ out, u32 b_gen, u32 B) {
     __shared__ u32 sh[256 * 27];
