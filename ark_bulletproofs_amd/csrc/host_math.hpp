@@ -188,8 +188,25 @@ template <class C> struct Grp {
         return F::sqr(p.y) == F::add(F::add(F::mul(F::sqr(p.x), p.x), F::mul(a, p.x)), b);
     }
     // ark-serialize 0.4 SW point encodings: flag 0x80 = y > -y, 0x40 = identity
-    static inline u8 y_flag(const A4& p) { return p.is_inf() ? 0x40 : (F::cmp_canon(p.y, F::neg(p.y)) > 0 ? 0x80 : 0x00); }
-    static inline void ser_uncompressed(u8 out[65], const A4& p) { F::to_bytes(out, p.x); F::to_bytes(out + 32, p.y); out[64] = y_flag(p); }
+    // ark-serialize's sign flag: y > -y, i.e. canonical y > (p - 1) / 2 = p >> 1 (p odd); one Montgomery product instead of three
+    static inline bool canon_gt_half(const u64 cy[4]) {
+        for (int i = 3; i >= 0; i--) {
+            const u64 h = (C::Fq::P64[i] >> 1) | (i < 3 ? (C::Fq::P64[i + 1] << 63) : 0);
+            if (cy[i] != h) return cy[i] > h;
+        }
+        return false;
+    }
+    static inline u8 y_flag(const A4& p) {
+        if (p.is_inf()) return 0x40;
+        u64 cy[4]; F::to_canon(cy, p.y);
+        return canon_gt_half(cy) ? 0x80 : 0x00;
+    }
+    static inline void ser_uncompressed(u8 out[65], const A4& p) {
+        u64 cx[4], cy[4];
+        F::to_canon(cx, p.x); F::to_canon(cy, p.y);
+        memcpy(out, cx, 32); memcpy(out + 32, cy, 32);
+        out[64] = p.is_inf() ? 0x40 : (canon_gt_half(cy) ? 0x80 : 0x00);
+    }
     static inline void ser_compressed(u8 out[33], const A4& p) { F::to_bytes(out, p.x); out[32] = y_flag(p); }
     static inline bool from_x(A4& o, const F4& x, bool greatest) {
         F4 a, b; memcpy(a.v, C::A64, 32); memcpy(b.v, C::B64, 32);

@@ -78,7 +78,15 @@ struct Strobe {
         meta_ad(label, n, false);
     }
     inline void runf() { st.b[pos] ^= pos_begin; st.b[pos + 1] ^= 0x04; st.b[RATE + 1] ^= 0x80; keccakf(st.w); pos = 0; pos_begin = 0; }
-    inline void absorb(const u8* d, size_t n) { for (size_t i = 0; i < n; i++) { st.b[pos++] ^= d[i]; if (pos == RATE) runf(); } }
+    inline void absorb(const u8* d, size_t n) {   // runs up to the rate boundary at a time (the inner loop vectorises)
+        while (n) {
+            const size_t take = n < (size_t)(RATE - pos) ? n : (size_t)(RATE - pos);
+            u8* dst = st.b + pos;
+            for (size_t i = 0; i < take; i++) dst[i] ^= d[i];
+            pos = (u8)(pos + take); d += take; n -= take;
+            if (pos == RATE) runf();
+        }
+    }
     inline void overwrite(const u8* d, size_t n) { for (size_t i = 0; i < n; i++) { st.b[pos++] = d[i]; if (pos == RATE) runf(); } }
     inline void squeeze(u8* d, size_t n) { for (size_t i = 0; i < n; i++) { d[i] = st.b[pos]; st.b[pos++] = 0; if (pos == RATE) runf(); } }
     inline void begin(u8 flags, bool more) {
