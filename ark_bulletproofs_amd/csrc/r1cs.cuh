@@ -161,10 +161,7 @@ k_vfy_scalars(const u32* __restrict__ wL, const u32* __restrict__ wR, const u32*
 //   sum_p alpha_p * g_p[i],  sum_p alpha_p * h_p[i],  sum_p (alpha_p r_p x_p^2) * y_p^-i wR_p[i] wL_p[i]   (the delta terms)
 // in registers.  Per-proof inputs are a 3.3 KB parameter block (power tables of z and y^-1, challenges, a, b, alpha).
 struct VfyTemplateDev {
-    const u32* col_off[3];   // n+1 each: W_L, W_R, W_O columns
-    const u32* ent_q;        // constraint index per entry
-    const u32* ent_c;        // coefficient id per entry
-    const u32* coefs;        // resident words
+    const u32* coefs;        // distinct coefficients, resident words
     const u32* m_off;        // n+1: per multiplier index i, the entries of W_L, W_R, W_O columns i merged and sorted by constraint
     const u32* m_ent;        // (vector << 30) | constraint index q     (vector 0 = W_L, 1 = W_R, 2 = W_O)
     const u32* m_c;          // coefficient id per merged entry
