@@ -23,7 +23,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+COLL_DEVICE = "cuda"   # where the collectives' tensors live ("cuda" over RCCL; None = CPU tensors over gloo, rehearsal only)
+
+
 def dist_setup(n_gpus):
+    """one process per GPU over RCCL.  Rehearsal on a one-GPU box: ARKBP_BENCH_REHEARSE=1 puts every rank on cuda:0 and runs the
+    collectives over gloo, so the multi-rank control flow can be exercised without a second GPU (numbers are meaningless)."""
+    global COLL_DEVICE
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -33,8 +39,14 @@ def dist_setup(n_gpus):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("ARKBP_BENCH_REHEARSE"):
+            local = 0
+            COLL_DEVICE = None
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     return rank, world, local
 
 
@@ -116,16 +128,16 @@ def run_msm(args, rank, world, local):
         if args.shard == "windows":
             # window-sharded MSM (north_star): every rank holds the same n terms and owns a range of Pippenger windows
             full = P.window_sharded_msm(args.curve, n, lambda lo, hi: eng.msm_dev_windows(db, ds, n, lo, hi), E.msm_window_count, E.host_points_sum,
-                                        rank, world, device="cuda" if world > 1 else None)
+                                        rank, world, device=COLL_DEVICE if world > 1 else None)
         else:
             # term-sharded MSM: local partial, all-gather of one 64-byte point per rank over RCCL, host point-reduce
-            full = P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device="cuda" if world > 1 else None)
+            full = P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device=COLL_DEVICE if world > 1 else None)
     barrier(world)
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
 
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE or "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     acc_ms, acc_n = eng.kernel_time(0)
@@ -187,7 +199,7 @@ def run_prove(args, rank, world, local):
         # the ranks must issue their per-MSM collectives in the same order)
         from ark_bulletproofs_amd import parallel as PP
 
-        PP.enable_window_sharding(engs[0], args.curve, E.host_points_sum, rank, world, device="cuda")
+        PP.enable_window_sharding(engs[0], args.curve, E.host_points_sum, rank, world, device=COLL_DEVICE)
 
     def make_statements(tag, count):
         out = [None] * count
@@ -262,7 +274,7 @@ def run_prove(args, rank, world, local):
     if world > 1:
         import torch.distributed as dist
 
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE or "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0].item())
     stages = np.zeros(8)
@@ -355,7 +367,7 @@ def run_verify(args, rank, world, local):
     ok = True
     for _ in range(args.steps):
         rc, tm, pt = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
-        parts = P.allgather_points(pt, device="cuda" if world > 1 else None)
+        parts = P.allgather_points(pt, device=COLL_DEVICE if world > 1 else None)
         ok = ok and rc == 0 and not E.host_points_sum(args.curve, parts).any()
         tms += np.array(tm)
     barrier(world)
@@ -363,7 +375,7 @@ def run_verify(args, rank, world, local):
     if world > 1:
         import torch.distributed as dist
 
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE or "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0].item())
     assert ok, "batch verification of valid proofs failed"
