@@ -162,7 +162,7 @@ def run_msm(args, rank, world, local):
         res["roofline"]["valu"] = {"unit": "G mixed adds/s", "achieved": madds / avg_s / 1e9, "peak": 12.9, "frac": madds / avg_s / 1e9 / 12.9,
                                    "note": "the kernel is integer-VALU-bound: gathered mixed Jacobian+affine additions (11 modular products each) against "
                                            "the measured add rate of this GPU (tools/ubench.hip, profiles/r01_ubench_radix29.txt)"}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         res["cpu_baseline"] = cpu_baseline_msm(args, bases, sc)
     db.free()
     ds.free()
@@ -326,7 +326,7 @@ def run_prove(args, rank, world, local):
                            "valu": {"unit": "G modmul/s", "achieved": modmul / per_proof_s / 1e9, "peak": 169.0, "frac": modmul / per_proof_s / 1e9 / 169.0,
                                     "note": "the path is integer-VALU-bound (about 3.9 k modular products per 192 algorithmic bytes of a fold): this is the "
                                             "fraction that measures the kernel; kernel times are from one proof run alone after the timed region"}}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         res["cpu_baseline"] = cpu_baseline_prove(args)
     for e in engs[1:] + engs[:1]:
         e.close()
@@ -404,7 +404,7 @@ def run_verify(args, rank, world, local):
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * N * nproofs_per_launch / avg_s / 1e9 / HBM_PEAK_GBS,
                            "traffic": pmc_traffic("verify4096/k_vfy_batch<Secq>", args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512, "r01_pmc_verify_4096_summary.json"),
                            "avg_kernel_ms": vs_ms / vs_n, "algorithmic_bytes_per_verify": per_proof_bytes}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         from oracle import pyoracle as O
 
         m = min(8, len(distinct))
