@@ -46,7 +46,7 @@ k_r1cs_poly_t(const u32* __restrict__ aL, const u32* __restrict__ aR, const u32*
         t[4] = fe_mul<F>(l2, r3);                                                   // t5 = <l2,r3>
         t[5] = fe_mul<F>(l3, r3);                                                   // t6 = <l3,r3>
     }
-#pragma unroll 1
+#pragma unroll   // (a rolled loop indexes t[] dynamically and sends the six accumulators through scratch: 440 MB of writes at N = 2^20)
     for (int k = 0; k < 6; k++) {
         Fe s = block_sum_fe<F>(fe_wred<F>(t[k]), sh);
         if (threadIdx.x == 0) store_fe_dev<F>(partials + ((size_t)blockIdx.x * 6 + k) * 8, s);
