@@ -164,7 +164,7 @@ struct VfyTemplateDev {
     const u32* coefs;        // distinct coefficients, resident words
     const u32* m_off;        // n+1: per multiplier index i, the entries of W_L, W_R, W_O columns i merged and sorted by constraint
     const u32* m_ent;        // (vector << 30) | constraint index q     (vector 0 = W_L, 1 = W_R, 2 = W_O)
-    const u32* m_c;          // coefficient id per merged entry
+    const u32* m_c;          // coefficient id per merged entry; bit 31 / bit 30 flag the coefficients +1 / -1
     const u32* const_q;      // constant terms (Variable::One) of the constraints: wc = -sum z^(q+1) * coef  (verifier.rs:339-341)
     const u32* const_c;
     u32 n_const;
@@ -253,7 +253,11 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chu
                     const u32 ent = t.m_ent[e], q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
                     if (q1 != cur) zp = fe_mul<F>(load_fe_dev<F>(Z + (size_t)(q1 & 255u) * 8), load_fe_dev<F>(Z + (size_t)(256u + (q1 >> 8)) * 8));
                     cur = q1;
-                    const Fe term = fe_mul<F>(zp, load_fe_dev<F>(t.coefs + (size_t)t.m_c[e] * 8));
+                    const u32 cid = t.m_c[e];   // bit 31: the coefficient is +1, bit 30: it is -1 (most gadget constraints): no product
+                    Fe term;
+                    if (cid & 0x80000000u) term = zp;
+                    else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zp));
+                    else term = fe_mul<F>(zp, load_fe_dev<F>(t.coefs + (size_t)cid * 8));
                     if (vec == 0) wL = fe_addr<F>(wL, term); else if (vec == 1) wR = fe_addr<F>(wR, term); else wO = fe_addr<F>(wO, term);
                 }
                 const Fe ywR = fe_mul<F>(yni, wR);
