@@ -354,6 +354,31 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     return finish_sharded(result);
 }
 
+// MSM over the resident generator tables (no base upload): bases = G[off..off+n) (if use_G) || H[off..off+n) (if use_H) || extras
+template <class C> static int msm_gens_entry(bp_ctx* c, int use_G, int use_H, size_t off, size_t n, const uint64_t* extra_xy, size_t n_extra,
+                                             const uint64_t* scalars, int canonical, uint64_t out_xy[8]) {
+    const size_t ng = use_G ? n : 0, nh = use_H ? n : 0, total = ng + nh + n_extra;
+    if (total == 0) { memset(out_xy, 0, 64); return BP_OK; }
+    BPCHK(c->io_scal.ensure(total * 32));
+    HIPCHK(hipMemcpyAsync(c->io_scal.p, scalars, total * 32, hipMemcpyHostToDevice, c->stream));
+    if (n_extra) {
+        BPCHK(c->io_pts.ensure(n_extra * 64));
+        HIPCHK(hipMemcpyAsync(c->io_pts.p, extra_xy, n_extra * 64, hipMemcpyHostToDevice, c->stream));
+        BPCHK(bp_points_import(c, c->io_pts.p, c->io_pts.p, n_extra));
+    }
+    BaseSegs sg; memset(&sg, 0, sizeof sg);
+    int k = 0; u32 at = 0;
+    if (ng) { sg.ptr[k] = c->d_G.as<u32>() + off * 16; sg.start[k] = at; at += (u32)ng; k++; }
+    if (nh) { sg.ptr[k] = c->d_H.as<u32>() + off * 16; sg.start[k] = at; at += (u32)nh; k++; }
+    if (n_extra) { sg.ptr[k] = c->io_pts.as<u32>(); sg.start[k] = at; at += (u32)n_extra; k++; }
+    sg.start[k] = at; sg.nseg = k;
+    J4 r;
+    BPCHK(msm_run<C>(c, sg, c->io_scal.as<u32>(), total, canonical ? 0 : 1, r));
+    A4 a = host::Grp<C>::to_aff(r);
+    memcpy(out_xy, a.x.v, 32); memcpy(out_xy + 4, a.y.v, 32);
+    if (c->profiling) collect_timers(c);
+    return BP_OK;
+}
 template <class C> static void aff_out(uint64_t out[8], const A4& a) { memcpy(out, a.x.v, 32); memcpy(out + 4, a.y.v, 32); }
 
 template <class C> static int msm_dev_entry(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int canonical, uint64_t out_xy[8],
@@ -982,6 +1007,17 @@ int bp_msm_dev(bp_ctx* c, const void* d_bases, const void* d_scalars, size_t n, 
     if (!c || !out_xy || ((!d_bases || !d_scalars) && n)) { g_err = "bp_msm_dev: bad argument"; return BP_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
     return c->curve == 0 ? msm_dev_entry<Secq>(c, d_bases, d_scalars, n, canonical, out_xy) : msm_dev_entry<Zorro>(c, d_bases, d_scalars, n, canonical, out_xy);
+}
+int bp_msm_gens(bp_ctx* c, int use_G, int use_H, size_t off, size_t n, const uint64_t* extra_bases_xy, size_t n_extra, const uint64_t* scalars,
+                int canonical, uint64_t out_xy[8]) {
+    if (!c || !out_xy || (n_extra && !extra_bases_xy)) { g_err = "bp_msm_gens: bad argument"; return BP_E_ARG; }
+    const size_t total = (use_G ? n : 0) + (use_H ? n : 0) + n_extra;
+    if (total && !scalars) { g_err = "bp_msm_gens: bad argument"; return BP_E_ARG; }
+    if ((use_G || use_H) && n && off + n > c->gens_cap) { g_err = "bp_msm_gens: range exceeds the installed generator tables"; return BP_E_GENS_LENGTH; }
+    if (total >= ((size_t)1 << 31)) { g_err = "bp_msm_gens: too many terms"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? msm_gens_entry<Secq>(c, use_G, use_H, off, n, extra_bases_xy, n_extra, scalars, canonical, out_xy)
+                         : msm_gens_entry<Zorro>(c, use_G, use_H, off, n, extra_bases_xy, n_extra, scalars, canonical, out_xy);
 }
 int bp_msm_window_count(int curve, size_t n, int* windows, int* window_bits) {
     if ((curve != 0 && curve != 1) || !windows) return BP_E_ARG;

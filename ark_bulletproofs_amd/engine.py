@@ -80,6 +80,17 @@ class Engine:
         check(lib().bp_msm(self.ctx, ptr(b), ptr(s), C.c_size_t(len(b)), int(canonical), ptr(out)), "bp_msm")
         return out
 
+    def msm_gens(self, n, scalars, use_G=True, use_H=True, off=0, extra_bases=None, canonical=False):
+        """MSM over the resident generator tables: G[off:off+n] || H[off:off+n] || extra_bases, scalars in that order"""
+        ex = u64arr(extra_bases, 8) if extra_bases is not None and len(extra_bases) else np.zeros((0, 8), dtype=np.uint64)
+        s = u64arr(scalars, 4)
+        if len(s) != (n if use_G else 0) + (n if use_H else 0) + len(ex):
+            raise ValueError("msm_gens: bases and scalars differ in length")
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().bp_msm_gens(self.ctx, int(use_G), int(use_H), C.c_size_t(off), C.c_size_t(n), ptr(ex) if len(ex) else None, C.c_size_t(len(ex)),
+                                ptr(s) if len(s) else None, int(canonical), ptr(out)), "bp_msm_gens")
+        return out
+
     def msm_dev(self, d_bases, d_scalars, n, canonical=False):
         out = np.zeros(8, dtype=np.uint64)
         check(lib().bp_msm_dev(self.ctx, d_bases.ptr, d_scalars.ptr, C.c_size_t(n), int(canonical), ptr(out)), "bp_msm_dev")

@@ -72,6 +72,14 @@ int bp_msm_window_count(int curve, size_t n, int* windows, int* window_bits);
 int bp_msm_dev_windows(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int scalars_canonical, int w_lo, int w_hi,
                        uint64_t out_xy[8]);
 
+/* MSM over the RESIDENT generator tables (bp_gens_derive / bp_gens_upload), for the prover's and verifier's own msm call sites
+ * (e.g. A_I = msm([B_blinding] ++ G[..n] ++ H[..n], ..), src/r1cs/prover.rs:516-559): bases = G[off..off+n) if use_G, then
+ * H[off..off+n) if use_H, then n_extra caller points (ark layout); scalars in the same order, (use_G ? n : 0) + (use_H ? n : 0) +
+ * n_extra of them (ark Montgomery words, or canonical integers when scalars_canonical).  Nothing but the scalars and the extra
+ * points crosses PCIe.  BP_E_GENS_LENGTH when the range exceeds the installed tables. */
+int bp_msm_gens(bp_ctx* ctx, int use_G, int use_H, size_t off, size_t n, const uint64_t* extra_bases_xy, size_t n_extra, const uint64_t* scalars,
+                int scalars_canonical, uint64_t out_xy[8]);
+
 /* Window-sharded mode for whole computations (north_star: "large proofs shard Pippenger windows across the GPUs of one node with
  * a final point-reduce"): after bp_ctx_set_window_shard(ctx, rank, world, cb, user) EVERY MSM this ctx runs (bp_msm*, the L/R
  * MSMs of bp_ipa_create, the commitment MSMs of the prover, the verifier's mega-check) accumulates only the windows of `rank`

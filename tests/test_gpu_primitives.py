@@ -271,3 +271,29 @@ def test_statement_built_on_gpu_equals_host_statement(eng):
         assert (ia[0] == ib[0]).all() and (ia[1] == ib[1]).all() and ia[2:] == ib[2:]
         a.free()
         b.free()
+
+
+def test_msm_over_resident_generator_tables(oracle):
+    """bp_msm_gens: the prover's msm call sites over BulletproofGens without re-uploading bases, e.g.
+    A_I = msm([B_blinding] ++ G[..n] ++ H[..n]) (src/r1cs/prover.rs:516-559)"""
+    import ark_bulletproofs_amd as A
+
+    O = oracle
+    for cv in (0, 1):
+        e = A.Engine(curve=cv)
+        e.gens_derive(300)
+        G, H = O.bp_gens(cv, 300)
+        _, Bb = O.pedersen_default(cv)
+        n = 257
+        sc = _rand_scalars(O, cv, 2 * n + 1, 77)
+        got = e.msm_gens(n, sc, extra_bases=Bb.reshape(1, 8))
+        assert (got == O.msm(cv, np.concatenate([G[:n], H[:n], Bb.reshape(1, 8)]), sc)).all()
+        # G only with an offset (phase-2 slices G[n1..]), H only, extras only, nothing
+        assert (e.msm_gens(40, sc[:40], use_H=False, off=100) == O.msm(cv, G[100:140], sc[:40])).all()
+        assert (e.msm_gens(40, sc[:41], use_G=False, off=260, extra_bases=G[:1]) == O.msm(cv, np.concatenate([H[260:300], G[:1]]), sc[:41])).all()
+        assert (e.msm_gens(0, sc[:3], extra_bases=H[5:8]) == O.msm(cv, H[5:8], sc[:3])).all()
+        assert not e.msm_gens(0, sc[:0]).any()
+        with pytest.raises(A.ArkbpError) as ei:
+            e.msm_gens(41, sc[:82], off=260)
+        assert ei.value.code == -5
+        e.close()
