@@ -1296,6 +1296,15 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src) {
     return BP_OK;
 }
 
+int bp_r1cs_verification_gh(bp_ctx* c, size_t n, size_t n1, const uint64_t* wL, const uint64_t* wR, const uint64_t* wO, const uint64_t y[4],
+                            const uint64_t x[4], const uint64_t u[4], const uint64_t a[4], const uint64_t b[4], const uint64_t* ipa_challenges, size_t k,
+                            uint64_t* g_out, uint64_t* h_out) {
+    if (!c || !y || !x || !u || !a || !b || !g_out || !h_out || (n && (!wL || !wR || !wO)) || (k && !ipa_challenges) || k >= 32) { g_err = "bp_r1cs_verification_gh: bad argument"; return BP_E_ARG; }
+    if (n > ((size_t)1 << k) || n1 > n) { g_err = "bp_r1cs_verification_gh: n exceeds the padded size 2^k"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? verification_gh_host_entry<Secq>(c, n, n1, wL, wR, wO, y, x, u, a, b, ipa_challenges, k, g_out, h_out)
+                         : verification_gh_host_entry<Zorro>(c, n, n1, wL, wR, wO, y, x, u, a, b, ipa_challenges, k, g_out, h_out);
+}
 int bp_ipa_verify(bp_ctx* c, size_t n, const uint64_t* G_factors, const uint64_t* H_factors, const uint64_t P_xy[8], const uint64_t Q_xy[8],
                   const uint64_t* G_xy, const uint64_t* H_xy, const uint64_t* L_xy, const uint64_t* R_xy, size_t lg_n, const uint64_t* challenges,
                   const uint64_t a[4], const uint64_t b[4]) {

@@ -399,6 +399,20 @@ def _batch_verify(self, instances, alpha_seed, alpha_skip=0, want_point=False):
     return rc, list(timing)
 
 
+def _verification_gh(self, n1, wL, wR, wO, y, x, u, a, b, ipa_challenges):
+    """g_scalars / h_scalars of Verifier::verification_scalars (canonical integers, 2^k each) from the caller's flattened vectors"""
+    wL, wR, wO = u64arr(wL, 4), u64arr(wR, 4), u64arr(wO, 4)
+    ch = u64arr(ipa_challenges, 4)
+    k = len(ch)
+    N = 1 << k
+    g, h = np.zeros((N, 4), dtype=np.uint64), np.zeros((N, 4), dtype=np.uint64)
+    sc = [np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (y, x, u, a, b)]
+    check(lib().bp_r1cs_verification_gh(self.ctx, C.c_size_t(len(wL)), C.c_size_t(n1), ptr(wL), ptr(wR), ptr(wO), *[ptr(v) for v in sc], ptr(ch),
+                                        C.c_size_t(k), ptr(g), ptr(h)), "bp_r1cs_verification_gh")
+    return g, h
+
+
+Engine.verification_gh = _verification_gh
 Engine.verify_scenario = _verify_scenario
 Engine.batch_verify = _batch_verify
 

@@ -239,6 +239,17 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
 #define BP_TUNE_IPA_FREEZE_LEN 2
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 
+/* The O(N) part of `Verifier::verification_scalars` (src/r1cs/verifier.rs:465-514, s from inner_product_proof.rs:279-311) for a
+ * caller that records constraints and replays the transcript itself: from the flattened wL, wR, wO (n each; zero beyond n), the
+ * challenges y, x, u (phase-2 separator), the proof's a, b and the k inner-product challenges u_j (creation order), with
+ * n1 phase-1 multipliers and padded size N = 2^k:
+ *   g[i] = u_or_1(i) * (x * y^-i * wR[i] - a * s[i]),   h[i] = u_or_1(i) * (y^-i * (x * wL[i] + wO[i] - b * s[N-1-i]) - 1),  i < N
+ * (u_or_1 = 1 for i < n1, u otherwise), written as CANONICAL integers — the form the mega-check MSM consumes (bp_msm_gens with
+ * scalars_canonical = 1).  All inputs ark Montgomery words. */
+int bp_r1cs_verification_gh(bp_ctx* ctx, size_t n, size_t n1, const uint64_t* wL, const uint64_t* wR, const uint64_t* wO, const uint64_t y[4],
+                            const uint64_t x[4], const uint64_t u[4], const uint64_t a[4], const uint64_t b[4], const uint64_t* ipa_challenges, size_t k,
+                            uint64_t* g_out, uint64_t* h_out);
+
 /* ---- unit-test hooks: one field / group operation per element on the GPU -------------------------- */
 /* field: 2*curve + (0 base field | 1 scalar field); op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inv */
 int bp_debug_field_op(bp_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

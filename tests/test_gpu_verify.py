@@ -218,3 +218,50 @@ def test_batch_pipeline_many_blocks(eng, oracle):
     if (np.asarray(mism[3][3]) != np.asarray(cm)).any():
         rc, _ = eng.batch_verify(mism, seed)
         assert rc == E_VERIFICATION
+
+
+def test_verification_gh_scalars_match_reference_formulas(eng, oracle):
+    """bp_r1cs_verification_gh against an independent big-integer evaluation of verifier.rs:465-514 / inner_product_proof.rs:279-311:
+    s[i] = prod_j u_j^(+1 if bit (k-1-j)... ) in the reference's doubling order, g and h with the phase separator u on i >= n1,
+    zero-padded wL/wR/wO beyond n."""
+    O, cv = oracle, eng.curve
+    FR = O.fid(cv, True)
+    r = O.modulus(FR)
+    import random
+
+    rnd = random.Random(5)
+    k, n, n1 = 6, 50, 20
+    N = 1 << k
+    val = lambda: rnd.randrange(1, r)   # noqa: E731
+    y, x, u, a, b = val(), val(), val(), val(), val()
+    ch = [val() for _ in range(k)]
+    wL = [rnd.randrange(r) for _ in range(n)]
+    wR = [rnd.randrange(r) for _ in range(n)]
+    wO = [rnd.randrange(r) for _ in range(n)]
+    wL[3] = wR[7] = wO[11] = 0
+    inv = lambda v: pow(v, r - 2, r)   # noqa: E731
+    # s vector exactly as the reference builds it (:302-311): s[0] = prod u_j^-1; s[i] = s[i - 2^lg] * u_sq[k-1-lg], lg = floor(log2 i)
+    allinv = 1
+    for c in ch:
+        allinv = allinv * inv(c) % r
+    u_sq = [c * c % r for c in ch]
+    s = [allinv]
+    for i in range(1, N):
+        lg = i.bit_length() - 1
+        s.append(s[i - (1 << lg)] * u_sq[k - 1 - lg] % r)
+    y_inv = inv(y)
+    g_exp, h_exp = [], []
+    for i in range(N):
+        wl = wL[i] if i < n else 0
+        wr = wR[i] if i < n else 0
+        wo = wO[i] if i < n else 0
+        yni = pow(y_inv, i, r)
+        uo1 = 1 if i < n1 else u
+        g_exp.append(uo1 * (x * yni * wr - a * s[i]) % r)
+        h_exp.append(uo1 * (yni * (x * wl + wo - b * s[N - 1 - i]) - 1) % r)
+    M = lambda v: O.fe_from_int(FR, v)   # noqa: E731
+    g, h = eng.verification_gh(n1, np.array([M(v) for v in wL]), np.array([M(v) for v in wR]), np.array([M(v) for v in wO]), M(y), M(x), M(u), M(a), M(b),
+                               np.array([M(c) for c in ch]))
+    got_g = [O.limbs_to_int(v) for v in g]
+    got_h = [O.limbs_to_int(v) for v in h]
+    assert got_g == g_exp and got_h == h_exp
