@@ -102,6 +102,7 @@ struct bp_ctx {
     DevBuf r_aL, r_aR, r_aO, r_sL, r_sR, r_wL, r_wR, r_wO, r_msmsc, r_ypow, r_part, r_small, r_g, r_h, r_chal, r_tail;
     // batch verification: per-proof parameter blocks, chunk partials; cached circuit templates (VTemplate<C>)
     DevBuf v_params, v_gpart, v_hpart, v_alpha, v_tables, v_dec;
+    DevBuf p_moff, p_ment, p_mc, p_coefs, p_ztab;   // prover-side constraint index of the statement being proved (k_r1cs_flatten)
     void* h_vstage[2] = {nullptr, nullptr};   // pinned staging halves of the batch-verify pipeline
     size_t h_vstage_cap[2] = {0, 0};
     hipEvent_t vstage_ev[2] = {nullptr, nullptr};
@@ -887,6 +888,7 @@ struct bp_stmt {
     std::unique_ptr<host::ConstraintSystem<Zorro>> cs1;
     ProvePre<Secq> pre0;
     ProvePre<Zorro> pre1;
+    std::unique_ptr<HostCsc> csc;   // constraint index of a single-phase statement (built with the statement)
     bool consumed = false;
     bp_stmt(int sc, const uint8_t* seed) : scenario(sc), tr(host::scenario_label(sc)), prng(seed) {}
 };
@@ -896,7 +898,11 @@ template <class C> static int stmt_build(bp_stmt* s, std::unique_ptr<host::Const
     host::TP<C>::r1cs_domain_sep(s->tr);
     host::PedersenGens<C> pc = host::PedersenGens<C>::make_default();
     if (ctx) pedersen_attach<C>(ctx, pc);
-    return host::scenario_prover<C>(*cs, pc, s->prng, s->scenario, params, s->io);
+    int rc = host::scenario_prover<C>(*cs, pc, s->prng, s->scenario, params, s->io);
+    if (rc) return rc;
+    s->csc.reset(new HostCsc());
+    if (!build_host_csc<C>(*cs, *s->csc)) s->csc.reset();
+    return BP_OK;
 }
 
 // ---- C ABI ----------------------------------------------------------------------------------------
@@ -929,7 +935,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
-                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec};
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab};
     c->templates.clear();
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -1252,7 +1258,7 @@ int bp_stmt_prove(bp_ctx* c, bp_stmt* s, uint8_t* proof_out, size_t* proof_len, 
     s->consumed = true;
     host::ProofData pf;
     StageTimes tm;
-    int rc = c->curve == 0 ? r1cs_prove<Secq>(c, *s->cs0, s->prng, pf, tm, &s->pre0) : r1cs_prove<Zorro>(c, *s->cs1, s->prng, pf, tm, &s->pre1);
+    int rc = c->curve == 0 ? r1cs_prove<Secq>(c, *s->cs0, s->prng, pf, tm, &s->pre0, s->csc.get()) : r1cs_prove<Zorro>(c, *s->cs1, s->prng, pf, tm, &s->pre1, s->csc.get());
     if (rc) return rc;
     std::vector<host::u8> bytes = c->curve == 0 ? host::proof_to_bytes<Secq>(pf) : host::proof_to_bytes<Zorro>(pf);
     if (bytes.size() > *proof_len) { g_err = "prove: output buffer too small"; return BP_E_ARG; }

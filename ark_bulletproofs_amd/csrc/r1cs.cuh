@@ -340,6 +340,42 @@ k_vfy_tail_scale(u32* __restrict__ tails, const u32* __restrict__ alphas, const 
     store_words8(tails + (size_t)j * 8, w);
 }
 
+// ---- prover-side flattened_constraints (src/r1cs/prover.rs:354-397) for single-phase statements ----------------------------
+// The recorded constraints are indexed once, at statement construction, as the merged CSC the verifier templates use (per
+// multiplier index i: the entries of columns i of W_L, W_R, W_O in constraint order); after the challenge z is known one launch
+// evaluates w_L, w_R, w_O = z^(q+1)-weighted column sums on the GPU instead of the host's pass over all terms + 3 uploads.
+// Z: 256 + nzhi resident scalars, z^e = Z[e & 255] * Z[256 + (e >> 8)].
+template <class C> __global__ void __launch_bounds__(256)
+k_r1cs_ztables(const u32* __restrict__ ztab /* z^(2^j), 32 resident scalars */, u32 nzhi, u32* __restrict__ Z) {
+    typedef typename C::Fr F;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 256) store_fe_dev<F>(Z + (size_t)t * 8, pow_table<F>(ztab, t));
+    if (t < nzhi) store_fe_dev<F>(Z + (size_t)(256 + t) * 8, pow_table<F>(ztab, t << 8));
+}
+template <class C> __global__ void __launch_bounds__(256)
+k_r1cs_flatten(const u32* __restrict__ m_off, const u32* __restrict__ m_ent, const u32* __restrict__ m_c, const u32* __restrict__ coefs,
+               const u32* __restrict__ Z, u32 n, u32* __restrict__ wL_out, u32* __restrict__ wR_out, u32* __restrict__ wO_out) {
+    typedef typename C::Fr F;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe wL = fe_zero<F>(), wR = fe_zero<F>(), wO = fe_zero<F>(), zp = fe_one<F>();
+    u32 cur = 0;
+    for (u32 e = m_off[i], e1 = m_off[i + 1]; e < e1; e++) {
+        const u32 ent = m_ent[e], q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z of constraint q is z^(q+1) (prover.rs:368-390)
+        if (q1 != cur) zp = fe_mul<F>(load_fe_dev<F>(Z + (size_t)(q1 & 255u) * 8), load_fe_dev<F>(Z + (size_t)(256u + (q1 >> 8)) * 8));
+        cur = q1;
+        const u32 cid = m_c[e];
+        Fe term;
+        if (cid & 0x80000000u) term = zp;
+        else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zp));
+        else term = fe_mul<F>(zp, load_fe_dev<F>(coefs + (size_t)cid * 8));
+        if (vec == 0) wL = fe_addr<F>(wL, term); else if (vec == 1) wR = fe_addr<F>(wR, term); else wO = fe_addr<F>(wO, term);
+    }
+    store_fe_dev<F>(wL_out + (size_t)i * 8, wL);
+    store_fe_dev<F>(wR_out + (size_t)i * 8, wR);
+    store_fe_dev<F>(wO_out + (size_t)i * 8, wO);
+}
+
 // resident form -> canonical integers, in place
 template <class F> __global__ void k_scalars_to_canon(u32* __restrict__ v, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
