@@ -159,6 +159,8 @@ static MsmPlan msm_plan(size_t n, int bits) {
         double cost = n * W + (n * W / MSM_CH + B) * 1.45 + B * (0.5 * c) * 1.45 + 256.0 * c * W * 0.05;
         if (cost < best) { best = cost; bc = c; }
     }
+    static const int c_env = getenv("ARKBP_MSM_C") ? atoi(getenv("ARKBP_MSM_C")) : 0;   // experiments
+    if (c_env >= 3 && c_env <= 16 && n >= 4096) bc = c_env;
     MsmPlan pl; pl.c = bc; pl.W = bits / bc + 1; pl.NB = 1 << (bc - 1); pl.B = (u32)pl.W * pl.NB; pl.n = (u32)n;
     pl.w_lo = 0; pl.w_hi = pl.W;
     return pl;
@@ -265,7 +267,8 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     int chl = MSM_CHL;
     u32 b_gen = pl.B;   // buckets below b_gen go through the generic reduction tree; the rest (narrow top window) are special
     auto front_end = [&](bool bins) -> int {
-        chl = bins ? MSM_CHL_BINNED : MSM_CHL;
+        static const int chl_env = getenv("ARKBP_MSM_CHL") ? atoi(getenv("ARKBP_MSM_CHL")) : 0;
+        chl = bins ? (chl_env >= 3 && chl_env <= 6 ? chl_env : MSM_CHL_BINNED) : MSM_CHL;
         static const bool no_special = getenv("ARKBP_MSM_NOSPECIAL") != nullptr;
         b_gen = (bins && bp.top_nb && bp.top_nb <= 16 && !no_special) ? (u32)bp.wb * (u32)pl.NB : pl.B;   // few, huge buckets only: a wider top window fits the generic tree
         const size_t nslots = make_slots(sp, bins ? (int)bp.wb : 0, bins ? (size_t)bp.wb * bp.NBIN * bp.cap : 0);
