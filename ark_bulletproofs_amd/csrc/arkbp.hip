@@ -87,6 +87,7 @@ struct bp_ctx {
     size_t tune_fold_batch_min = 65536;   // BP_TUNE_FOLD_BATCH_MIN
     size_t tune_msm_bin_min = 64;         // BP_TUNE_MSM_BIN_MIN
     size_t tune_ipa_freeze_len = 1024;    // BP_TUNE_IPA_FREEZE_LEN
+    size_t tune_msm_wsum_min = (size_t)1 << 18;   // BP_TUNE_MSM_WSUM_MIN: buckets from which running-sum window aggregation replaces the marginals
     KTimer timers[BP_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // MSM workspaces
@@ -205,9 +206,13 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     BPCHK(ctx->lvl_off.ensure(Bp1 * NL * 4));
     BPCHK(ctx->totals.ensure((NL + 2) * 4 + (size_t)ntiles * (NL + 1) * 4));
     BPCHK(ctx->cursor.ensure(pl.B * 4));
-    BPCHK(ctx->Tbuf.ensure((size_t)pl.W * pl.c * 96));
+    static const bool force_marginals = getenv("ARKBP_MSM_MARGINALS") != nullptr;   // A/B: the bit-marginal bucket aggregation everywhere
+    const bool use_marginals = force_marginals || pl.B < ctx->tune_msm_wsum_min;
+    const u32 nblk_ws = (u32)((pl.NB + 256 * MSM_SEG - 1) / (256 * MSM_SEG));   // workgroups per window of k_msm_window_sums
+    const size_t tcount = use_marginals ? (size_t)pl.W * pl.c : (size_t)pl.W * nblk_ws;
+    BPCHK(ctx->Tbuf.ensure(tcount * 96));
     if (!ctx->h_totals) HIPCHK(hipHostMalloc((void**)&ctx->h_totals, 64));
-    const size_t tbytes = (size_t)pl.W * pl.c * 96;
+    const size_t tbytes = tcount * 96;
     if (ctx->h_T_cap < tbytes) {
         if (ctx->h_T) HIPCHK(hipHostFree(ctx->h_T));
         HIPCHK(hipHostMalloc((void**)&ctx->h_T, tbytes + 4096));
@@ -339,19 +344,28 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
             hipLaunchKernelGGL(k_msm_reduce_special<C>, dim3(bp.top_nb), dim3(256), 0, st, cur, lvl + Bp1 * spl, lvl + Bp1 * (spl + 1), nxt, b_gen, pl.B);
         u32* t = cur; cur = nxt; nxt = t;
     }
-    hipLaunchKernelGGL(k_msm_marginals<C>, dim3(pl.W, pl.c), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl);
+    if (use_marginals) hipLaunchKernelGGL(k_msm_marginals<C>, dim3(pl.W, pl.c), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl);
+    else hipLaunchKernelGGL(k_msm_window_sums<C>, dim3(nblk_ws, pl.W), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl, nblk_ws);
     HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tbytes, hipMemcpyDeviceToHost, st));
     total.stop();
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
-    // host tail: sum_{w,k} 2^(c*w+k) T[w][k], Horner from the top bit down
     J4 acc = G::inf();
     const u64* T = (const u64*)ctx->h_T;
-    for (int j = pl.W * pl.c - 1; j >= 0; j--) {
-        acc = G::dbl(acc);
-        const u64* t = T + (size_t)j * 12;
+    auto add_T = [&](size_t idx) {
+        const u64* t = T + idx * 12;
         J4 p; memcpy(p.X.v, t, 32); memcpy(p.Y.v, t + 4, 32); memcpy(p.Z.v, t + 8, 32);
         if (!p.Z.is_zero()) acc = G::add(acc, p);
+    };
+    if (use_marginals) {
+        // host tail: sum_{w,k} 2^(c*w+k) T[w][k], Horner from the top bit down
+        for (int j = pl.W * pl.c - 1; j >= 0; j--) { acc = G::dbl(acc); add_T((size_t)j); }
+    } else {
+        // host tail: sum_w 2^(c*w) * (sum_j T[w][j]), Horner over the windows (c doublings of ONE point between them)
+        for (int w = pl.W - 1; w >= 0; w--) {
+            for (int d = 0; d < pl.c; d++) acc = G::dbl(acc);
+            for (u32 j = 0; j < nblk_ws; j++) add_T((size_t)w * nblk_ws + j);
+        }
     }
     (void)sizeof(F);
     result = acc;
@@ -960,6 +974,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
         case BP_TUNE_FOLD_BATCH_MIN: c->tune_fold_batch_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_BIN_MIN: c->tune_msm_bin_min = (size_t)value; return BP_OK;
         case BP_TUNE_IPA_FREEZE_LEN: c->tune_ipa_freeze_len = (size_t)value; return BP_OK;
+        case BP_TUNE_MSM_WSUM_MIN: c->tune_msm_wsum_min = (size_t)value; return BP_OK;
     }
     return BP_E_ARG;
 }

@@ -123,6 +123,7 @@ def test_msm_two_level_sort_forced_small(eng, oracle):
     """two-level sort with a handful of terms (bins of a few entries, empty bins, the narrow top window in LDS)"""
     O, cv = oracle, eng.curve
     eng.set_tuning(1, 1)
+    eng.set_tuning(3, 1)      # running-sum window aggregation for every bucket count
     try:
         for n in (1, 2, 31, 33, 257, 1000):
             G, H = O.bp_gens(cv, max(n, 2))
@@ -131,6 +132,7 @@ def test_msm_two_level_sort_forced_small(eng, oracle):
             assert (eng.msm(bases, sc) == O.msm(cv, bases, sc)).all()
     finally:
         eng.set_tuning(1, 64)
+        eng.set_tuning(3, 1 << 18)
 
 
 def test_msm_two_level_sort_sizes(eng, oracle):

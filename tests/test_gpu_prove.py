@@ -59,6 +59,7 @@ def test_prove_large_round_kernels_at_small_sizes(oracle, sc, prm, freeze):
         e.set_tuning(0, 1)
         e.set_tuning(1, 1)
         e.set_tuning(2, freeze)
+        e.set_tuning(3, 1 if freeze else 1 << 18)   # running-sum window aggregation at small sizes too
         ref = oracle.r1cs_prove(cv, sc, prm, SEED, 128, m_cap=128)
         got = e.prove_scenario(sc, prm, SEED, m_cap=128)
         assert got.proof == ref.proof and (got.commitments == ref.commitments).all()
