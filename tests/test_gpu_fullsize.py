@@ -121,3 +121,31 @@ def test_cfg3_shuffle_statement_full_size():
         assert e.verify_scenario(E.SC_SHUFFLE, [k], proof, swapped, pubs) == -4
     finally:
         e.close()
+
+
+def test_zorro_prove_verify_roundtrip_2pow16_and_batch():
+    """the second curve of cfg5 (zorro: a = 6, 255-bit scalar field, no endomorphism -> plain NAF fold ladder) at full-size
+    kernels: prove -> verify -> tamper at 2^16, and a mixed batch through the block pipeline"""
+    import ark_bulletproofs_amd as A
+
+    e = A.Engine(curve=1)
+    try:
+        N = 1 << 16
+        e.gens_derive(N)
+        pr = e.prove_scenario(3, [N, 0], bytes([6]) * 32, m_cap=8)
+        assert len(pr.proof) == 539 + 66 * 16
+        assert e.verify_scenario(3, [N, 0], pr.proof, pr.commitments, pr.publics) == 0
+        bad = bytearray(pr.proof)
+        bad[11 * 33 + 70] ^= 1   # e_blinding
+        assert e.verify_scenario(3, [N, 0], bytes(bad), pr.commitments, pr.publics) == -4
+        inst = [(3, [N, 0], pr.proof, pr.commitments, pr.publics)]
+        for i in range(3):
+            p2 = e.prove_scenario(4, [64, 32, 0], bytes([7, i] + [7] * 30), m_cap=72)
+            inst.append((4, [64, 32, 0], p2.proof, p2.commitments, p2.publics))
+        rc, _ = e.batch_verify(inst, bytes([8]) * 32)
+        assert rc == 0
+        inst[2] = (4, [64, 32, 0], inst[3][2], inst[2][3], inst[2][4])   # proof of another statement
+        rc, _ = e.batch_verify(inst, bytes([8]) * 32)
+        assert rc == -4
+    finally:
+        e.close()
