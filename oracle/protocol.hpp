@@ -456,7 +456,7 @@ struct Prover : CS {
         Err e = create_randomized_constraints();
         if (e) return e;
 
-        size_t n = a_L.size(), n2 = n - n1, padded_n = next_pow2(n), pad = padded_n - n;
+        size_t n = a_L.size(), n2 = n - n1, padded_n = next_pow2(n);
         if (bp.gens_capacity < padded_n) return E_GENS_LENGTH;
         bool has2 = n2 > 0;
         Fe i_b2 = F.Z, o_b2 = F.Z, s_b2 = F.Z;
