@@ -1224,7 +1224,9 @@ int bp_r1cs_verify_scenario(bp_ctx* c, int scenario, const uint64_t* params, con
 int bp_r1cs_batch_verify_scenarios(bp_ctx* c, size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs, const size_t* proof_lens,
                                    const uint64_t* commit_xy, const size_t* ms, const uint64_t* publics, const size_t* npubs, const uint8_t alpha_seed[32],
                                    double* timing, size_t alpha_skip, uint64_t* check_point_xy) {
-    if (!c || !count || !scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !npubs || !alpha_seed) return BP_E_ARG;
+    if (!c) return BP_E_ARG;
+    if (count == 0) { if (check_point_xy) memset(check_point_xy, 0, 64); return BP_OK; }   // the reference's mega-check of nothing is the identity (verifier.rs:685-690)
+    if (!scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !npubs || !alpha_seed) return BP_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; return BP_E_GENS_LENGTH; }
     return c->curve == 0 ? batch_verify_scenarios<Secq>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy)

@@ -370,6 +370,16 @@ class PackedInstances:
     def __init__(self, instances):
         n = len(instances)
         self.n = n
+        if n == 0:   # an empty batch is valid (the reference's mega-check of nothing is the identity)
+            self.scen = (C.c_int * 1)()
+            self.prm = np.zeros(8, dtype=np.uint64)
+            self.proofs = b""
+            self.plens = (C.c_size_t * 1)()
+            self.cms = np.zeros((1, 8), dtype=np.uint64)
+            self.ms = (C.c_size_t * 1)()
+            self.pubs = np.zeros((1, 4), dtype=np.uint64)
+            self.npubs = (C.c_size_t * 1)()
+            return
         self.scen = (C.c_int * n)(*[i[0] for i in instances])
         self.prm = np.concatenate([_prm(i[1]) for i in instances])
         self.proofs = b"".join(i[2] for i in instances)

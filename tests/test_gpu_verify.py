@@ -93,6 +93,8 @@ def test_batch_range_proof_gadget(eng, oracle):
 
 def test_batch_mixed_scenarios_and_many(eng, oracle):
     O, cv = oracle, eng.curve
+    rc, _, pt = eng.batch_verify([], bytes([6]) * 32, want_point=True)   # empty batch: Ok, like the reference's MSM of nothing
+    assert rc == OK and not pt.any()
     inst = []
     for i in range(12):
         sc, prm = [(0, [5]), (3, [20, 0]), (1, [8, 200]), (4, [2, 8, 0])][i % 4]
