@@ -310,31 +310,43 @@ template <class C> struct ConstraintSystem {
     static void lc_sub(LinComb& a, const LinComb& b) { for (auto& t : b) a.push_back(Term{t.v, S::neg(t.c)}); }
     static void lc_add(LinComb& a, const LinComb& b) { a.insert(a.end(), b.begin(), b.end()); }
 
-    F4 eval(const LinComb& lc) const {  // prover.rs:399-414
+    // The recording primitives take (terms, count): gadget code keeps its short linear combinations on the stack, and a C caller's
+    // arrays arrive in this shape (bp_cs_multiply / bp_cs_constrain); the LinComb overloads below are conveniences.
+    F4 eval(const Term* lc, size_t cnt) const {  // prover.rs:399-414
         F4 acc = S::zero();
-        for (auto& t : lc) {
-            F4 val;
+        const F4 one = S::one();
+        for (size_t j = 0; j < cnt; j++) {
+            const Term& t = lc[j];
+            const F4* val;
             switch (t.v.k) {
-                case VK_LEFT: val = a_L[t.v.i]; break;
-                case VK_RIGHT: val = a_R[t.v.i]; break;
-                case VK_OUT: val = a_O[t.v.i]; break;
-                case VK_COMMITTED: val = v[t.v.i]; break;
-                default: val = S::one(); break;
+                case VK_LEFT: val = &a_L[t.v.i]; break;
+                case VK_RIGHT: val = &a_R[t.v.i]; break;
+                case VK_OUT: val = &a_O[t.v.i]; break;
+                case VK_COMMITTED: val = &v[t.v.i]; break;
+                default: val = &one; break;
             }
-            acc = S::add(acc, S::mul(t.c, val));
+            acc = S::add(acc, t.c == one ? *val : S::mul(t.c, *val));
         }
         return acc;
     }
-    void constrain(const LinComb& lc) { cs_terms.insert(cs_terms.end(), lc.begin(), lc.end()); cs_off.push_back(cs_terms.size()); }
-    // multiply (prover.rs:103-133 / verifier.rs:74-98)
-    void multiply(LinComb left, LinComb right, Var out[3]) {
-        u32 i = (u32)num_vars++;
-        if (proving) { F4 l = eval(left), r = eval(right); a_L.push_back(l); a_R.push_back(r); a_O.push_back(S::mul(l, r)); }
-        out[0] = Var{VK_LEFT, i}; out[1] = Var{VK_RIGHT, i}; out[2] = Var{VK_OUT, i};
-        F4 m1 = S::neg(S::one());
-        left.push_back(Term{out[0], m1}); right.push_back(Term{out[1], m1});
-        constrain(left); constrain(right);
+    F4 eval(const LinComb& lc) const { return eval(lc.data(), lc.size()); }
+    // room for a gadget of known size (the vectors otherwise grow by doubling: ~2x peak memory at 2^20+ multipliers)
+    void reserve(size_t multipliers, size_t constraints, size_t terms) {
+        cs_terms.reserve(cs_terms.size() + terms); cs_off.reserve(cs_off.size() + constraints);
+        if (proving) { a_L.reserve(a_L.size() + multipliers); a_R.reserve(a_R.size() + multipliers); a_O.reserve(a_O.size() + multipliers); }
     }
+    void constrain(const Term* lc, size_t cnt) { cs_terms.insert(cs_terms.end(), lc, lc + cnt); cs_off.push_back(cs_terms.size()); }
+    void constrain(const LinComb& lc) { constrain(lc.data(), lc.size()); }
+    // multiply (prover.rs:103-133 / verifier.rs:74-98): constraints left - l = 0 and right - r = 0
+    void multiply(const Term* left, size_t nl, const Term* right, size_t nr, Var out[3]) {
+        u32 i = (u32)num_vars++;
+        if (proving) { F4 l = eval(left, nl), r = eval(right, nr); a_L.push_back(l); a_R.push_back(r); a_O.push_back(S::mul(l, r)); }
+        out[0] = Var{VK_LEFT, i}; out[1] = Var{VK_RIGHT, i}; out[2] = Var{VK_OUT, i};
+        const F4 m1 = S::neg(S::one());
+        cs_terms.insert(cs_terms.end(), left, left + nl); cs_terms.push_back(Term{out[0], m1}); cs_off.push_back(cs_terms.size());
+        cs_terms.insert(cs_terms.end(), right, right + nr); cs_terms.push_back(Term{out[1], m1}); cs_off.push_back(cs_terms.size());
+    }
+    void multiply(const LinComb& left, const LinComb& right, Var out[3]) { multiply(left.data(), left.size(), right.data(), right.size(), out); }
     // allocate (prover.rs:135-157 / verifier.rs:100-116)
     int allocate(const F4* assignment, Var& out) {
         if (proving && !assignment) return BP_E_MISSING;
@@ -503,7 +515,8 @@ template <class C> static int scenario_prover(ConstraintSystem<C>& cs, const Ped
             if (prm[1]) last = S::add(last, S::one());
             Var cur = commit(x0, b), o[3];
             io.publics.push_back(last);
-            for (size_t i = 0; i < N; i++) { cs.multiply(cs.lc_var(cur), cs.lc_var(cur), o); cur = o[2]; }
+            cs.reserve(N, 2 * N + 1, 4 * N + 2);
+            for (size_t i = 0; i < N; i++) { const Term t{cur, S::one()}; cs.multiply(&t, 1, &t, 1, o); cur = o[2]; }
             LinComb lc = cs.lc_var(cur); CS::lc_sub(lc, cs.lc_const(last)); cs.constrain(lc);
             return BP_OK;
         }
@@ -558,7 +571,8 @@ template <class C> static int scenario_verifier(ConstraintSystem<C>& cs, int sc,
         case SC_SQUARE_CHAIN: {
             if (io.commitments.size() != 1 || io.publics.size() != 1) return BP_E_ARG;
             Var cur = commit(io.commitments[0]), o[3];
-            for (size_t i = 0; i < prm[0]; i++) { cs.multiply(cs.lc_var(cur), cs.lc_var(cur), o); cur = o[2]; }
+            cs.reserve(prm[0], 2 * prm[0] + 1, 4 * prm[0] + 2);
+            for (size_t i = 0; i < prm[0]; i++) { const Term t{cur, S::one()}; cs.multiply(&t, 1, &t, 1, o); cur = o[2]; }
             LinComb lc = cs.lc_var(cur); CS::lc_sub(lc, cs.lc_const(io.publics[0])); cs.constrain(lc);
             return BP_OK;
         }

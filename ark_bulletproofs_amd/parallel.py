@@ -139,7 +139,12 @@ def enable_window_sharding(engine, curve, points_sum, rank, world, group=None, d
 def sharded_batch_verify(curve, instances, local_batch_verify, points_sum, rank, world, group=None, device=None):
     """instances: the FULL ordered instance list (every rank passes the same list); rank r verifies its block with
     alpha_skip = lo_r.  local_batch_verify(slice, alpha_skip) -> (status, check_point).  Returns 0 iff the batch is valid.
-    A rank with an error other than VerificationError (malformed proof, missing generators) fails the batch."""
+
+    The batch is valid iff EVERY rank's status is 0.  A rank's batch_verify can fail before its mega-check MSM runs (an identity
+    A_I1 / T_i / L_j, a truncated L_vec, a malformed proof: src/r1cs/verifier.rs:420-470 return early) and then has no check
+    point to contribute, so the point sum alone must never decide: the statuses are max-reduced first.  The sum of the ranks'
+    check points (by linearity the reference's single MSM, :685) is kept as a consistency check on top.  The first hard error
+    (anything but VerificationError) wins over -4, as the reference's `?` returns the first error."""
     import torch
     import torch.distributed as dist
 
@@ -147,15 +152,20 @@ def sharded_batch_verify(curve, instances, local_batch_verify, points_sum, rank,
     status, pt = 0, np.zeros(8, dtype=np.uint64)
     if hi > lo:
         status, pt = local_batch_verify(instances[lo:hi], lo)
-    hard_error = status not in (0, -4)
+    if status != 0:
+        pt = np.zeros(8, dtype=np.uint64)   # a failed rank's buffer is not a check point
     parts = allgather_points(pt, group, device)
     total = points_sum(curve, parts)
+    worst = status
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        flag = torch.tensor([1 if hard_error else 0], dtype=torch.int64)
+        # statuses are <= 0; order them so that hard errors beat -4 beats 0: key = 0 (ok), 1 (-4), 2 + |code| (hard error)
+        key = 0 if status == 0 else 1 if status == -4 else 2 + abs(int(status))
+        flag = torch.tensor([key], dtype=torch.int64)
         if device is not None:
             flag = flag.to(device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-        hard_error = bool(flag.item())
-    if hard_error:
-        return status if status not in (0, -4) else -4
+        key = int(flag.item())
+        worst = 0 if key == 0 else -4 if key == 1 else -(key - 2)
+    if worst != 0:
+        return worst
     return 0 if not total.any() else -4

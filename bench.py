@@ -1,18 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — measures the MSM / inner-product hot path on MI355X and prints ONE JSON line.
 
-  python bench.py --gpus N --steps K --warmup W [--workload msm|prove]
+  python bench.py --gpus N --steps K --warmup W [--workload headline|prove|verify|msm]
 
-A "step" is one pass of the hot path over one batch of synthetic, HBM-resident input.  For N > 1 the
-driver launches one rank per GPU with torch.distributed.run; units are sharded across ranks (weak
-scaling), the only exchange is the all-gather of one partial point per rank.
+BASELINE.json's metric has two halves — R1CS constraints proved/s and batch verifies/s — so the default workload
+("headline") runs both on the same box: the top-level fields are the prove half (cfg3: 2^20-constraint proofs), and the
+"verify" object carries the batch-verify half (cfg4: 4096 proofs of 2^14 constraints per GPU) with its own value, roofline
+and cpu_baseline.  The reference's own benchmark workload is benches/r1cs_secq256k1.rs:156-190 (prove) and :201-250 (verify).
 
-Only the `cpu_baseline` leg touches oracle/ (the CPU restatement), as the timed CPU reference.
+A "step" is one pass of the hot path over one batch of synthetic input.  `--gpus N` with N > 1 and no WORLD_SIZE in the
+environment starts N ranks itself (torch.distributed.run, one process per GPU, before this process touches the GPU); under a
+launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  Units are sharded across ranks (weak scaling); the only exchange is the
+all-gather of one 64-byte partial point per rank.
+
+Documented multi-GPU commands (SCALE): `bench.py --gpus N` (prove replicas + proof-sharded verify),
+`bench.py --gpus N --workload verify`, `bench.py --gpus N --workload prove --shard windows --logn 22` (cfg5: one proof at a
+time, Pippenger windows and the IPA folds partitioned across the ranks), `bench.py --gpus N --workload msm --shard windows`.
+
+Only the `cpu_baseline` legs touch oracle/ (the CPU restatement), as the timed CPU reference, after the timed regions.
 """
 import argparse
 import json
 import os
+import queue
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -21,9 +35,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-
+DTYPE = "u32x9 (256-bit modular integers, radix 2^29)"
+CURVES = ["secq256k1", "zorro"]
 
 COLL_DEVICE = "cuda"   # where the collectives' tensors live ("cuda" over RCCL; None = CPU tensors over gloo, rehearsal only)
+
+
+def statement_seed(tag, k):
+    """32-byte ChaCha20 seed of synthetic statement k of a run (tag separates warmup / timed / isolated statements);
+    the same on every rank, valid for any k < 2^32"""
+    return bytes([3 + (tag & 0x7F)]) + int(k).to_bytes(4, "little") + bytes([3]) * 27
+
+
+def spawn_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) from this process, which has not
+    touched the GPU, and exit with their status.  Never re-execs a process that has initialised HIP."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def dist_setup(n_gpus):
@@ -60,11 +95,40 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
+def max_over_ranks(dt, world):
+    if world <= 1:
+        return dt
+    import torch
+    import torch.distributed as dist
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE or "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt[0].item())
+
+
+def run_threads(targets):
+    """starts one thread per (fn, args) and joins them all; the first exception raised in any of them is re-raised here
+    (a worker failure must fail the bench, not surface three frames later as a None)"""
+    errors = []
+
+    def guard(fn, a):
+        try:
+            fn(*a)
+        except BaseException as e:  # noqa: BLE001 — re-raised below
+            errors.append(e)
+
+    th = [threading.Thread(target=guard, args=(fn, a)) for fn, a in targets]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
+
+
 def synth_msm_inputs(eng, n, rank):
     """cfg2 inputs without the (slow, sequential) generator derivation: bases = k_i * G for a seeded k_i
     computed ON THE GPU by the engine's own scalar-mul kernel; scalars = seeded 256-bit values < r."""
-    import ark_bulletproofs_amd as A  # noqa: F401
-
     rng = np.random.default_rng(1234 + rank)
     gen = {0: (53718550993811904772965658690407829053653678808745171666022356150019200052646,
                28941648020349172432234515805717979317553499307621291159490218670604692907903,
@@ -108,8 +172,6 @@ def pmc_traffic(keys, applicable, fname, field="largest"):
 
 
 def run_msm(args, rank, world, local):
-    import torch
-
     import ark_bulletproofs_amd as A
     from ark_bulletproofs_amd import engine as E
     from ark_bulletproofs_amd import parallel as P
@@ -127,28 +189,22 @@ def run_msm(args, rank, world, local):
     for _ in range(args.steps):
         if args.shard == "windows":
             # window-sharded MSM (north_star): every rank holds the same n terms and owns a range of Pippenger windows
-            full = P.window_sharded_msm(args.curve, n, lambda lo, hi: eng.msm_dev_windows(db, ds, n, lo, hi), E.msm_window_count, E.host_points_sum,
-                                        rank, world, device=COLL_DEVICE if world > 1 else None)
+            P.window_sharded_msm(args.curve, n, lambda lo, hi: eng.msm_dev_windows(db, ds, n, lo, hi), E.msm_window_count, E.host_points_sum,
+                                 rank, world, device=COLL_DEVICE if world > 1 else None)
         else:
             # term-sharded MSM: local partial, all-gather of one 64-byte point per rank over RCCL, host point-reduce
-            full = P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device=COLL_DEVICE if world > 1 else None)
+            P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device=COLL_DEVICE if world > 1 else None)
     barrier(world)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-
-        tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE or "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0, world)
     acc_ms, acc_n = eng.kernel_time(0)
     tot_ms, tot_n = eng.kernel_time(1)
     res = {
         "metric": "msm_terms_per_sec", "value": n * (1 if args.shard == "windows" else world) * args.steps / dt, "unit": "terms/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.shard == "windows" else "weak", "vs_baseline": None,
-        "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
-        "config": {"workload": "cfg2: 2^%d-term variable-base MSM, %s, inputs HBM-resident" % (int(np.log2(n)), ["secq256k1", "zorro"][args.curve]),
-                   "terms_per_gpu": n, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": "%s-sharded x%d" % (args.shard[:-1], world)},
+        "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": "cfg2: 2^%d-term variable-base MSM, %s, inputs HBM-resident" % (int(np.log2(n)), CURVES[args.curve]),
+                   "terms_per_gpu": n, "curve": CURVES[args.curve], "parallelism": "%s-sharded x%d" % (args.shard[:-1], world)},
     }
     if acc_n:
         avg_s = acc_ms / acc_n * 1e-3
@@ -170,29 +226,127 @@ def run_msm(args, rank, world, local):
     return res
 
 
+class ProvePipeline:
+    """The prove workload's three stages, all inside the timed region:
+
+      build   (host pool)  Prover::new + commit + gadget for statement k (the reference's benchmark builds these inside its
+                           timed closure too, benches/r1cs_secq256k1.rs:172-184).  At most `window` statements are alive at once
+                           (built, not yet proved): a 2^20 statement holds ~0.3 GB of witness + constraints.
+      stage 1 (host pool)  the head of prove(): the TranscriptRng chain — 8 sequential Keccak-f per multiplier, the reference's
+                           design — for groups of 8 consecutive statements in AVX-512 lockstep.
+      stage 2 (P drivers)  the rest of prove() on the GPU, one ctx/stream each; a proved statement is freed at once.
+
+    The chain of proof k+1 overlaps the GPU work of proof k.  Results come back in `out` (index = statement number)."""
+
+    def __init__(self, E, engs, args, N):
+        self.E, self.engs, self.args, self.N = E, engs, args, N
+
+    def run(self, tag, count, out):
+        E, args, engs = self.E, self.args, self.engs
+        window = max(16, 2 * args.batch)
+        built = [None] * count
+        built_ev = [threading.Event() for _ in range(count)]
+        slots = threading.Semaphore(window)
+        stop = threading.Event()
+        lock = threading.Lock()
+        nxt_build, nxt_pre = [0], [0]
+        ready = queue.Queue()
+
+        def wait(ev_or_sem, is_sem=False):
+            while not stop.is_set():
+                if (ev_or_sem.acquire(timeout=0.2) if is_sem else ev_or_sem.wait(0.2)):
+                    return True
+            return False
+
+        def guarded(fn):
+            def w(*a):
+                try:
+                    fn(*a)
+                except BaseException:
+                    stop.set()
+                    raise
+            return w
+
+        @guarded
+        def build():
+            while not stop.is_set():
+                with lock:
+                    k = nxt_build[0]
+                    nxt_build[0] += 1
+                if k >= count:
+                    return
+                if not wait(slots, True):
+                    return
+                built[k] = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [self.N, 0], statement_seed(tag, k))
+                built_ev[k].set()
+
+        @guarded
+        def stage1():
+            while not stop.is_set():
+                with lock:
+                    i = nxt_pre[0]
+                    nxt_pre[0] += 8
+                if i >= count:
+                    return
+                grp = list(range(i, min(i + 8, count)))
+                for g in grp:
+                    if not wait(built_ev[g]):
+                        return
+                E.precompute_batch([built[g] for g in grp])   # 8 chains in lockstep in AVX-512 lanes (Keccak-f x8)
+                for g in grp:
+                    ready.put(g)
+
+        @guarded
+        def stage2(k):
+            while True:
+                try:
+                    i = ready.get(timeout=0.2)
+                except queue.Empty:
+                    if stop.is_set():
+                        return
+                    continue
+                if i is None:
+                    return
+                out[i] = built[i].prove(engs[k])
+                built[i].free()   # a consumed statement (witness + constraints, ~0.3 GB at 2^20) is released at once
+                built[i] = None
+                slots.release()
+
+        def producers():
+            run_threads([(build, ())] * args.build_threads + [(stage1, ())] * args.host_threads)
+            for _ in engs:
+                ready.put(None)
+
+        try:
+            run_threads([(producers, ())] + [(stage2, (k,)) for k in range(len(engs))])
+        finally:
+            stop.set()
+            for s in built:
+                if s is not None:
+                    s.free()
+        missing = [i for i, r in enumerate(out) if r is None]
+        if missing:
+            raise RuntimeError("prove pipeline: %d statements were not proved (first: %d)" % (len(missing), missing[0]))
+
+
 def run_prove(args, rank, world, local):
     """cfg3: R1CS proofs of a 2^logn-multiplier circuit (square chain: 1 commitment, N multiply gates, q = 2N+1 linear
-    constraints).  A step = one batch of `inflight` independent proofs on this GPU, each on its own ctx/stream with its own
-    host thread, all reading one resident copy of the generator tables: the per-proof TranscriptRng chain (8 sequential
-    Keccak-f per multiplier, the reference's design) of one proof overlaps the GPU work of the others.  Statement
-    construction (commits + gadget, outside the reference's prove()) happens before the timed region.
-    `value` = padded multiplication gates proved / wall seconds.  N > 1 ranks: replicas (weak scaling)."""
-    import threading
-
-    import torch
-
+    constraints).  A step = one batch of `batch` independent proofs on this GPU; `inflight` of them are on the GPU at a time,
+    each on its own ctx/stream with its own host thread, all reading one resident copy of the generator tables.
+    `value` = padded multiplication gates proved / wall seconds.  N > 1 ranks: replicas (weak scaling), or with
+    --shard windows every rank works on the SAME proof (cfg5 partition, strong scaling)."""
     import ark_bulletproofs_amd as A
     from ark_bulletproofs_amd import engine as E
 
     N = 1 << args.logn
-    P = 1 if (args.shard == "windows" and world > 1) else max(1, args.inflight)
+    window_sharded = args.shard == "windows" and world > 1
+    P = 1 if window_sharded else max(1, args.inflight)
     engs = [A.Engine(curve=args.curve, device=local) for _ in range(P)]
     t0 = time.perf_counter()
     engs[0].gens_derive(N)
     t_gens = time.perf_counter() - t0
     for e in engs[1:]:
         e.share_gens_from(engs[0])
-    window_sharded = args.shard == "windows" and world > 1
     if window_sharded:
         # north_star / cfg5 partition: all ranks prove the SAME statements; every MSM inside prove() accumulates the rank's Pippenger
         # windows and the partial points are summed over RCCL (strong scaling of one proof at a time: one proof in flight, because
@@ -200,93 +354,27 @@ def run_prove(args, rank, world, local):
         from ark_bulletproofs_amd import parallel as PP
 
         PP.enable_window_sharding(engs[0], args.curve, E.host_points_sum, rank, world, device=COLL_DEVICE)
-
-    def make_statements(tag, count):
-        out = [None] * count
-
-        def mk(k):
-            out[k] = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], bytes([3 + tag, 1 + (k & 0xFF), k >> 8] + [3] * 29))   # same on every rank
-
-        for lo in range(0, count, 16):   # at most 16 statements under construction at once
-            th = [threading.Thread(target=mk, args=(k,)) for k in range(lo, min(lo + 16, count))]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-        return out
-
-    def run_pool(stmts, out):
-        """Two stages, all inside the timed region.  Stage 1 (host pool): the head of prove() — TranscriptRng chain, 8
-        sequential Keccak-f per multiplier — for statements in order.  Stage 2 (P GPU drivers, one ctx/stream each): the rest
-        of prove().  The chain of proof k+1 overlaps the GPU work of proof k."""
-        import queue
-
-        ready = queue.Queue()
-        lock = threading.Lock()
-        nxt = [0]
-
-        def stage1():
-            while True:
-                with lock:
-                    i = nxt[0]
-                    nxt[0] += 8
-                if i >= len(stmts):
-                    return
-                grp = list(range(i, min(i + 8, len(stmts))))
-                E.precompute_batch([stmts[g] for g in grp])   # 8 chains in lockstep in AVX-512 lanes (Keccak-f x8)
-                for g in grp:
-                    ready.put(g)
-
-        def stage2(k):
-            while True:
-                i = ready.get()
-                if i is None:
-                    return
-                out[i] = stmts[i].prove(engs[k])
-                stmts[i].free()   # a consumed statement (witness + constraints, ~0.3 GB at 2^20) is released at once
-
-        t1 = [threading.Thread(target=stage1) for _ in range(args.host_threads)]
-        t2 = [threading.Thread(target=stage2, args=(k,)) for k in range(P)]
-        for t in t1 + t2:
-            t.start()
-        for t in t1:
-            t.join()
-        for _ in t2:
-            ready.put(None)
-        for t in t2:
-            t.join()
-
+    pipe = ProvePipeline(E, engs, args, N)
     if args.warmup:
-        ws = make_statements(100, args.batch * args.warmup)
-        run_pool(ws, [None] * len(ws))
-        del ws
+        pipe.run(100, args.batch * args.warmup, [None] * (args.batch * args.warmup))
     for e in engs:
         e.set_profiling(True)
         e.reset_profiling()
-    stmts = make_statements(0, args.batch * args.steps)   # untimed: statements (commits + gadget) exist before the timed region
-    flat = [None] * len(stmts)
+    nproofs = args.batch * args.steps
+    flat = [None] * nproofs
     barrier(world)
     t0 = time.perf_counter()
-    run_pool(stmts, flat)                        # K steps x P proofs
+    pipe.run(0, nproofs, flat)                   # K steps x `batch` proofs, statement construction included
     barrier(world)
-    dt = time.perf_counter() - t0
-    results = [flat]
-    if world > 1:
-        import torch.distributed as dist
-
-        tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE or "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0].item())
+    dt = max_over_ranks(time.perf_counter() - t0, world)
     stages = np.zeros(8)
-    for r in results:
-        for (_, tm) in r:
-            stages += np.array(tm)
-    nproofs = args.batch * args.steps
+    for (_, tm) in flat:
+        stages += np.array(tm)
     # kernel durations for the roofline: ONE more proof, alone on the GPU, after the timed region — HIP-event times taken while
     # several streams share the GPU include the other streams' kernels
     for e in engs:
         e.reset_profiling()
-    iso = make_statements(200, 1)[0]
+    iso = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], statement_seed(120, 0))
     iso.precompute()
     iso.prove(engs[0])
     iso.free()
@@ -297,10 +385,12 @@ def run_prove(args, rank, world, local):
     res = {
         "metric": "r1cs_constraints_proved_per_sec", "value": N * (1 if window_sharded else world) * nproofs / dt, "unit": "constraints/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if window_sharded else "weak",
-        "vs_baseline": None, "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
-        "config": {"workload": "cfg3: 2^%d-constraint R1CS prove (square-chain circuit, m=1, q=2N+1), %s, a step = %d independent proofs per GPU (%d GPU streams, %d host threads for the TranscriptRng stage)"
-                               % (args.logn, ["secq256k1", "zorro"][args.curve], args.batch, P, args.host_threads),
-                   "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "curve": ["secq256k1", "zorro"][args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": "cfg3: 2^%d-constraint R1CS prove (square-chain circuit, m=1, q=2N+1), %s, a step = %d independent proofs per GPU (%d GPU streams, %d host threads for the "
+                               "TranscriptRng stage, %d for statement construction, which is inside the timed region)"
+                               % (args.logn, CURVES[args.curve], args.batch, P, args.host_threads, args.build_threads),
+                   "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "build_threads": args.build_threads,
+                   "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
                    "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
@@ -338,8 +428,6 @@ def run_verify(args, rank, world, local):
     circuit, m = 256: n = 16384, q = 33024).  The instance list is built from `--distinct` distinct proofs (proved on the GPU
     before the timed region) repeated round-robin; every instance is replayed, alpha-scaled and accumulated separately.
     A step = one batch_verify call per rank over its shard of whole proofs; ranks exchange one 64-byte check point."""
-    import torch
-
     import ark_bulletproofs_amd as A
     from ark_bulletproofs_amd import engine as E
     from ark_bulletproofs_amd import parallel as P
@@ -350,7 +438,7 @@ def run_verify(args, rank, world, local):
     eng.gens_derive(N)
     distinct = []
     for i in range(args.distinct):
-        pr = eng.prove_scenario(E.SC_MULTI_RANGE, [nval, nbits, 0], bytes([4, i & 0xFF, i >> 8] + [4] * 29), m_cap=nval + 8)
+        pr = eng.prove_scenario(E.SC_MULTI_RANGE, [nval, nbits, 0], statement_seed(1, i), m_cap=nval + 8)
         distinct.append((E.SC_MULTI_RANGE, [nval, nbits, 0], pr.proof, pr.commitments, pr.publics))
     total = args.proofs * world
     lo, hi = P.shard_range(total, rank, world)
@@ -358,7 +446,7 @@ def run_verify(args, rank, world, local):
     inst = E.pack_instances(inst_list)   # the C ABI's flat arrays, marshalled once (a host in the reference's language owns them already)
     seed = bytes([5]) * 32
     for _ in range(args.warmup):
-        eng.batch_verify(inst_list[: max(8, len(inst_list) // 8)], seed)
+        eng.batch_verify(inst, seed, alpha_skip=lo)
     eng.set_profiling(True)
     eng.reset_profiling()
     barrier(world)
@@ -371,13 +459,7 @@ def run_verify(args, rank, world, local):
         ok = ok and rc == 0 and not E.host_points_sum(args.curve, parts).any()
         tms += np.array(tm)
     barrier(world)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-
-        tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE or "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0].item())
+    dt = max_over_ranks(time.perf_counter() - t0, world)
     assert ok, "batch verification of valid proofs failed"
     k = 14
     per_proof_bytes = 352 * N + 96 * (13 + nval + 2 * k)
@@ -385,9 +467,9 @@ def run_verify(args, rank, world, local):
     res = {
         "metric": "r1cs_batch_verifies_per_sec", "value": total * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32x9 (256-bit modular integers, radix 2^29)", "data": "synthetic",
+        "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "cfg4: batch_verify of %d R1CS proofs per GPU, 2^14 constraints each (256 x 64-bit range proofs, m=256), %s"
-                               % (args.proofs, ["secq256k1", "zorro"][args.curve]),
+                               % (args.proofs, CURVES[args.curve]),
                    "proofs_per_gpu": args.proofs, "distinct_proofs": len(distinct), "constraints_per_proof": N, "parallelism": "proof-sharded x%d" % world,
                    "stage_ms_per_step": {"whole_call": tms[0] / args.steps * 1e3, "host_replay_overlapped_with_gpu": tms[1] / args.steps * 1e3,
                                          "gpu_drain_and_tail_scaling": tms[2] / args.steps * 1e3, "final_msm": tms[3] / args.steps * 1e3,
@@ -395,7 +477,6 @@ def run_verify(args, rank, world, local):
     }
     if vs_n:
         avg_s = vs_ms / vs_n * 1e-3
-        # k_vfy_scalars per launch (one proof): reads wL, wR, wO (96*N B), read-modify-writes the shared g/h accumulators (128*N B)
         # k_vfy_batch (one launch per block of proofs): per proof it stands for the reference's scalar generation (64*N B written, 96*N B of
         # wL/wR/wO read) — 160*N algorithmic bytes per proof; the fused kernel itself reads only the 3.3 KB parameter
         # block per proof and the shared CSC, and writes chunk partials
@@ -407,12 +488,13 @@ def run_verify(args, rank, world, local):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         from oracle import pyoracle as O
 
-        m = min(8, len(distinct))
+        m = max(1, min(args.cpu_verify_proofs, total))
+        sample = [distinct[i % len(distinct)] for i in range(m)]
         tim = []
-        rc = O.batch_verify(args.curve, distinct[:m], N, seed, timing=tim)
+        rc = O.batch_verify(args.curve, sample, N, seed, timing=tim)
         assert rc == 0
         res["cpu_baseline"] = {"value": m / tim[0], "unit": "proofs/s", "cores": 1, "kind": "port",
-                               "sample": "batch_verify of %d of the same proofs (%.1f s), reference algorithm restated in C++" % (m, tim[0])}
+                               "sample": "batch_verify of the first %d instances of the same batch (%.1f s), reference algorithm restated in C++" % (m, tim[0])}
     eng.close()
     return res
 
@@ -440,18 +522,29 @@ def cpu_baseline_msm(args, bases, sc):
             "sample": "%d-term MSM (same bases/scalars), ark window schedule, single thread" % m}
 
 
+def run_headline(args, rank, world, local):
+    """both halves of BASELINE.json's metric on one box: prove (top level), then batch verify ("verify")"""
+    res = run_prove(args, rank, world, local)
+    ver = run_verify(args, rank, world, local)
+    res["metric"] = "r1cs_constraints_proved_per_sec (+ r1cs_batch_verifies_per_sec under \"verify\")"
+    res["verify"] = ver
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="prove", choices=["prove", "verify", "msm"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
     ap.add_argument("--logn", type=int, default=20)
-    ap.add_argument("--cpu-logn", type=int, default=13)
+    ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
+    ap.add_argument("--cpu-verify-proofs", type=int, default=256, help="CPU baseline sample of the verify workload (about 10 s)")
     ap.add_argument("--batch", type=int, default=16, help="independent proofs per step per GPU (prove workload)")
     ap.add_argument("--host-threads", type=int, default=3, help="host threads running the TranscriptRng head of prove()")
+    ap.add_argument("--build-threads", type=int, default=3, help="host threads constructing statements (Prover::new + commit + gadget)")
     ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--terms", type=int, default=1 << 16)
     ap.add_argument("--shard", default="terms", choices=["terms", "windows"],
@@ -459,10 +552,12 @@ def main():
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))        # this process has not touched the GPU
     rank, world, local = dist_setup(args.gpus)
-    res = {"msm": run_msm, "prove": run_prove, "verify": run_verify}[args.workload](args, rank, world, local)
+    res = {"msm": run_msm, "prove": run_prove, "verify": run_verify, "headline": run_headline}[args.workload](args, rank, world, local)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
 

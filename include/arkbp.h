@@ -207,8 +207,10 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src);
  * inside the block loop (overlapped with the GPU), [2] wait for the GPU after the last block + tail scaling, [3] final MSM,
  * [4] proof decoding (framing + point decompression).  Proof-sharded multi-GPU use: rank r passes its slice of the instances, alpha_skip = number
  * of instances on lower ranks (their alphas are drawn and discarded), and receives the affine value of ITS mega-check
- * in check_point_xy (may be NULL); the batch is valid iff the sum of all ranks' points is the identity
- * (bp_host_points_sum after an all-gather) — by linearity that sum is the reference's single MSM (:685). */
+ * in check_point_xy (may be NULL).  The batch is valid iff EVERY rank's call returned BP_OK (then every check point is the
+ * identity, and so is their sum — by linearity the reference's single MSM, :685).  A call can fail before its MSM runs (an
+ * identity A_I1 / T_i / L_j, mismatched L_vec, malformed bytes: verifier.rs:420-470 return early); check_point_xy is then
+ * all-zero, so the point sum alone must never decide — reduce the statuses first (parallel.sharded_batch_verify). */
 int bp_r1cs_verify_scenario(bp_ctx* ctx, int scenario, const uint64_t* params, const uint8_t* proof, size_t proof_len, const uint64_t* commit_xy,
                             size_t m, const uint64_t* publics, size_t npub);
 int bp_r1cs_batch_verify_scenarios(bp_ctx* ctx, size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs,

@@ -53,3 +53,56 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "pyoracle" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("Independent of oracle/", ""), f
+
+
+def test_bench_statement_seeds_do_not_overflow():
+    """bench.py derives one 32-byte ChaCha20 seed per synthetic statement; the driver's `--steps 20 --warmup 5` needs
+    400 of them (round 1 crashed at k = 255)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seeds = {bench.statement_seed(tag, k) for tag in (0, 1, 100, 120) for k in list(range(1200)) + [65535, 65536, (1 << 32) - 1]}
+    assert len(seeds) == 4 * 1203 and all(len(s) == 32 for s in seeds)
+
+
+def test_bench_worker_exceptions_propagate():
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def boom():
+        raise ValueError("worker failed")
+
+    with pytest.raises(ValueError):
+        bench.run_threads([(boom, ()), ((lambda: None), ())])
+
+
+def test_bench_gpus_flag_spawns_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (round 1 silently ran one)"""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert "torch.distributed.run" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4" and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"]

@@ -129,6 +129,21 @@ def _alpha_worker(rank, world, port, q):
                 return (0 if rc == 0 else -4), (np.zeros(8, dtype=np.uint64) if rc == 0 else O.generator(cv))
 
             res[tag] = P.sharded_batch_verify(cv, inst, local, E.host_points_sum, rank, world)
+
+            def local_early(slice_, skip):
+                # what the engine returns when a shard fails BEFORE its mega-check MSM (identity A_I1, truncated L_vec, ...):
+                # VerificationError with an all-zero check-point buffer.  The sum of the points is then the identity although
+                # the batch is invalid: the statuses must decide.
+                rc = O.batch_verify(cv, slice_, 128, bytes([5]) * 32)
+                return (0 if rc == 0 else -4), np.zeros(8, dtype=np.uint64)
+
+            res[tag + "_early"] = P.sharded_batch_verify(cv, inst, local_early, E.host_points_sum, rank, world)
+
+            def local_hard(slice_, skip):
+                # a malformed proof on the last rank only (FormatError = -6): the hard error wins on every rank
+                return (-6 if rank == world - 1 else 0), np.zeros(8, dtype=np.uint64)
+
+            res[tag + "_hard"] = P.sharded_batch_verify(cv, inst, local_hard, E.host_points_sum, rank, world)
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -149,6 +164,8 @@ def test_sharded_batch_verify_gloo_world2():
         assert p.exitcode == 0
     for rank, out in res:
         assert out["ok"] == 0 and out["bad"] == -4, (rank, out)
+        assert out["ok_early"] == 0 and out["bad_early"] == -4, (rank, out)   # a failed rank with an identity point fails the batch
+        assert out["ok_hard"] == -6 and out["bad_hard"] == -6, (rank, out)
 
 
 class _OracleIpaStepper:
