@@ -19,6 +19,11 @@ EXPORTS = [
     "bp_host_derive_generators", "bp_transcript_new", "bp_transcript_free", "bp_transcript_append_message", "bp_transcript_challenge_bytes",
     "bp_transcript_append_point", "bp_transcript_challenge_scalar", "bp_host_sha3_512", "bp_host_points_sum", "bp_debug_rng_draws", "bp_r1cs_prove_scenario", "bp_stmt_prover_create", "bp_stmt_free", "bp_stmt_info", "bp_stmt_prove", "bp_stmt_precompute", "bp_stmt_precompute_batch", "bp_gens_share", "bp_r1cs_verification_gh", "bp_r1cs_verify_scenario", "bp_r1cs_batch_verify_scenarios", "bp_ctx_set_profiling", "bp_ctx_kernel_time", "bp_ctx_reset_profiling",
     "bp_debug_decompress", "bp_debug_field_op", "bp_debug_point_op", "bp_debug_glv_decompose", "bp_ctx_set_tuning", "bp_ctx_set_window_shard", "bp_pedersen_commit_batch", "bp_stmt_prover_create_dev",
+    # r1cs::ConstraintSystem / Prover / Verifier for the caller's own gadgets
+    "bp_prover_new", "bp_verifier_new", "bp_verifier_new_like", "bp_cs_free", "bp_cs_transcript", "bp_cs_metrics", "bp_prover_commit", "bp_verifier_commit",
+    "bp_cs_multiply", "bp_cs_allocate", "bp_cs_allocate_multiplier", "bp_cs_constrain", "bp_cs_allocate_multipliers", "bp_cs_constrain_many",
+    "bp_cs_specify_randomized_constraints", "bp_cs_challenge_scalar", "bp_prover_set_rng", "bp_prover_precompute", "bp_prover_precompute_batch", "bp_prover_prove",
+    "bp_verifier_verify", "bp_r1cs_batch_verify", "bp_stmt_as_prover", "bp_transcript_export_state", "bp_transcript_import_state", "bp_transcript_clone",
 ]
 
 
@@ -40,6 +45,9 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.bp_last_error.restype = C.c_char_p
         _lib.bp_transcript_new.restype = C.c_void_p
+        _lib.bp_transcript_clone.restype = C.c_void_p
+        _lib.bp_cs_transcript.restype = C.c_void_p
+        _lib.bp_stmt_as_prover.restype = C.c_void_p
     return _lib
 
 

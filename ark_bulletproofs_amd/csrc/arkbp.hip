@@ -111,7 +111,11 @@ struct bp_ctx {
     size_t h_dec_cap = 0;
     hipStream_t aux_stream = nullptr;         // point decompression runs beside the main stream
     hipEvent_t dec_ev[2] = {nullptr, nullptr};
-    std::map<std::string, std::shared_ptr<void>> templates;
+    std::map<std::string, std::shared_ptr<void>> templates;          // structure digest -> VTemplate<C>
+    std::map<std::string, std::shared_ptr<void>> scenario_sources;   // (scenario, params, publics) -> recorded, frozen verifier
+    size_t scenario_source_terms = 0;
+    void* h_vaux[2] = {nullptr, nullptr};     // pinned: launch order + per-instance coefficient tables of a block
+    size_t h_vaux_cap[2] = {0, 0};
     // window-sharded multi-GPU mode (bp_ctx_set_window_shard): every MSM of this ctx accumulates only this rank's Pippenger
     // windows and the ranks' partial points are summed through the host's collective
     int shard_rank = 0, shard_world = 1;
@@ -894,33 +898,230 @@ template <class C> static int dbg_rng_draws(void* transcript, const uint64_t* wi
 #endif
 }
 
-// ---- statements (see include/arkbp.h) ----
-struct bp_stmt {
+// ---- recorder handles (see include/arkbp.h): a Prover<G, T> or Verifier<G, T> of the reference as seen through the C ABI ----
+struct bp_cs {
     int curve = 0;
-    int scenario = 0;
-    host::Transcript tr;
-    host::ChaChaRng prng;
-    host::StatementIO io;
+    bool proving = false;
+    host::Transcript* tr = nullptr;                 // the caller's transcript handle (borrowed, like `T: BorrowMut<Transcript>`)
+    std::unique_ptr<host::Transcript> owned_tr;     // statements own theirs
     std::unique_ptr<host::ConstraintSystem<Secq>> cs0;
     std::unique_ptr<host::ConstraintSystem<Zorro>> cs1;
     ProvePre<Secq> pre0;
     ProvePre<Zorro> pre1;
-    std::unique_ptr<HostCsc> csc;   // constraint index of a single-phase statement (built with the statement)
-    bool consumed = false;
-    bp_stmt(int sc, const uint8_t* seed) : scenario(sc), tr(host::scenario_label(sc)), prng(seed) {}
+    std::unique_ptr<HostCsc> csc;                   // constraint index of a single-phase statement (built on first need, outside prove())
+    bool csc_tried = false;
+    host::u8 rng32[32] = {0};                       // what prove() draws from the external rng
+    bool have_rng = false;
+    bool consumed = false;                          // prove(self) / verify(self)
+    bool running = false;                           // inside prove / verify: the randomized-phase callbacks may still record
+    std::vector<A4> commitments;                    // V points in commit order (both modes)
+    virtual ~bp_cs() {}
+    template <class C> host::ConstraintSystem<C>* cs();
+    size_t num_vars() const { return curve == 0 ? cs0->num_vars : cs1->num_vars; }
+    size_t num_constraints() const { return curve == 0 ? cs0->num_constraints() : cs1->num_constraints(); }
 };
-template <class C> static int stmt_build(bp_stmt* s, std::unique_ptr<host::ConstraintSystem<C>>& cs, const uint64_t* params, bp_ctx* ctx = nullptr) {
-    cs.reset(new host::ConstraintSystem<C>());
-    cs->tr = &s->tr; cs->proving = true;
-    host::TP<C>::r1cs_domain_sep(s->tr);
+template <> host::ConstraintSystem<Secq>* bp_cs::cs<Secq>() { return cs0.get(); }
+template <> host::ConstraintSystem<Zorro>* bp_cs::cs<Zorro>() { return cs1.get(); }
+// scenario statements: a prover handle plus what the scenario made public
+struct bp_stmt : bp_cs {
+    int scenario = 0;
+    host::StatementIO io;
+};
+
+template <class C> static void cs_handle_init(bp_cs* h, bool proving, host::Transcript* tr) {
+    h->curve = C::ID; h->proving = proving; h->tr = tr;
+    auto* cs = new host::ConstraintSystem<C>();
+    cs->tr = tr; cs->proving = proving; cs->owner = h;
+    if (C::ID == 0) h->cs0.reset((host::ConstraintSystem<Secq>*)cs); else h->cs1.reset((host::ConstraintSystem<Zorro>*)cs);
+    host::TP<C>::r1cs_domain_sep(*tr);   // Prover::new (prover.rs:291-308) / Verifier::new (verifier.rs:252-263)
+}
+template <class C> static int stmt_build(bp_stmt* s, const uint64_t* params, const uint8_t* seed, bp_ctx* ctx = nullptr) {
+    s->owned_tr.reset(new host::Transcript(host::scenario_label(s->scenario)));
+    cs_handle_init<C>(s, true, s->owned_tr.get());
+    host::ChaChaRng prng(seed);
     host::PedersenGens<C> pc = host::PedersenGens<C>::make_default();
     if (ctx) pedersen_attach<C>(ctx, pc);
-    int rc = host::scenario_prover<C>(*cs, pc, s->prng, s->scenario, params, s->io);
+    int rc = host::scenario_prover<C>(*s->cs<C>(), pc, prng, s->scenario, params, s->io);
     if (rc) return rc;
+    s->commitments = s->io.commitments;
+    prng.fill_bytes(s->rng32, 32); s->have_rng = true;   // the scenario's external rng is consumed by prove() for exactly these bytes
     s->csc.reset(new HostCsc());
-    if (!build_host_csc<C>(*cs, *s->csc)) s->csc.reset();
+    if (!build_host_csc<C>(*s->cs<C>(), *s->csc)) s->csc.reset();
+    s->csc_tried = true;
     return BP_OK;
 }
+template <class C> static int cs_prove(bp_ctx* c, bp_cs* s, uint8_t* proof_out, size_t* proof_len, double* timing) {
+    host::ProofData pf;
+    StageTimes tm;
+    auto* pre = C::ID == 0 ? (ProvePre<C>*)&s->pre0 : (ProvePre<C>*)&s->pre1;
+    if (!s->csc_tried) {   // single-phase circuits: the constraint index is statement construction, not prove()
+        s->csc.reset(new HostCsc());
+        if (!build_host_csc<C>(*s->cs<C>(), *s->csc)) s->csc.reset();
+        s->csc_tried = true;
+    }
+    int rc = r1cs_prove<C>(c, *s->cs<C>(), s->rng32, pf, tm, pre, s->csc.get());
+    if (rc) return rc;
+    std::vector<host::u8> bytes = host::proof_to_bytes<C>(pf);
+    if (bytes.size() > *proof_len) { g_err = "prove: output buffer too small"; return BP_E_ARG; }
+    memcpy(proof_out, bytes.data(), bytes.size()); *proof_len = bytes.size();
+    if (timing) { timing[0] = tm.total; timing[1] = 0; timing[2] = tm.rng; timing[3] = tm.upload; timing[4] = tm.commit_msm; timing[5] = tm.flatten; timing[6] = tm.poly; timing[7] = tm.ipa; }
+    return BP_OK;
+}
+template <class C> static int cs_precompute_batch(bp_cs** hs, size_t count) {
+    for (size_t g = 0; g < count; g += 8) {
+        const size_t c = std::min<size_t>(8, count - g);
+        host::ConstraintSystem<C>* css[8]; ProvePre<C>* pres[8]; const host::u8* rngs[8];
+        for (size_t j = 0; j < c; j++) {
+            css[j] = hs[g + j]->cs<C>(); rngs[j] = hs[g + j]->rng32;
+            pres[j] = C::ID == 0 ? (ProvePre<C>*)&hs[g + j]->pre0 : (ProvePre<C>*)&hs[g + j]->pre1;
+        }
+        prove_precompute_batch<C>(css, rngs, pres, c);
+    }
+    return BP_OK;
+}
+// batch_verify over recorded verifier handles (each consumed, like `verify(self)`)
+template <class C>
+static int cs_batch_verify(bp_ctx* c, size_t count, bp_cs* const* vs, const uint8_t* proofs, const size_t* proof_lens, const uint64_t* alphas, double* timing,
+                           uint64_t* point_out) {
+    typedef host::Fld<typename C::Fr> S;
+    std::vector<size_t> poff(count + 1, 0);
+    for (size_t k = 0; k < count; k++) poff[k + 1] = poff[k] + proof_lens[k];
+    std::vector<F4> al(count);
+    for (size_t k = 0; k < count; k++) { if (alphas) memcpy(al[k].v, alphas + 4 * k, 32); else al[k] = S::one(); }
+    VfyProvider<C> prov;
+    prov.m_of = [&](size_t k) { return vs[k]->cs<C>()->V.size(); };
+    prov.get = [&](size_t k, VfyInstance<C>& out) -> int { out.cs = vs[k]->cs<C>(); return BP_OK; };
+    for (size_t k = 0; k < count; k++) { vs[k]->consumed = true; vs[k]->running = true; }
+    const int rc = batch_verify_core<C>(c, count, prov, proofs, poff.data(), al.data(), timing, point_out);
+    for (size_t k = 0; k < count; k++) vs[k]->running = false;
+    return rc;
+}
+
+// ---- helpers of the bp_cs entry points (templates cannot live inside extern "C") ----
+#define CS_DISPATCH(h, expr0, expr1) ((h)->curve == 0 ? (expr0) : (expr1))
+// ---- r1cs::Prover / Verifier / ConstraintSystem for a caller's own gadgets -----------------------------------------------------
+static inline bool cs_live(bp_cs* h) { return h && (!h->consumed || h->running); }
+static inline void terms_in(std::vector<host::Term>& out, const bp_var* vars, const uint64_t* coefs, size_t n) {
+    out.resize(n);
+    for (size_t i = 0; i < n; i++) { out[i].v.k = (host::VKind)vars[i].kind; out[i].v.i = vars[i].index; memcpy(out[i].c.v, coefs + 4 * i, 32); }
+}
+template <class C> static bool terms_valid(bp_cs* h, const bp_var* vars, size_t n) {
+    const host::ConstraintSystem<C>& cs = *h->cs<C>();
+    const size_t m = cs.proving ? cs.v.size() : cs.V.size();
+    for (size_t i = 0; i < n; i++) {
+        if (vars[i].kind > BP_VAR_ONE) return false;
+        if (vars[i].kind == BP_VAR_COMMITTED ? vars[i].index >= m : vars[i].kind != BP_VAR_ONE && vars[i].index >= cs.num_vars) return false;
+    }
+    return true;
+}
+static inline bp_var var_out(const host::Var& v) { bp_var o; o.kind = (uint32_t)v.k; o.index = v.i; return o; }
+template <class C> static int verifier_new_like(bp_cs* of, host::Transcript* tr, bp_cs** out) {
+    host::ConstraintSystem<C>& src = *of->cs<C>();
+    BPCHK(src.freeze());
+    bp_cs* h = new bp_cs();
+    cs_handle_init<C>(h, false, tr);
+    h->cs<C>()->init_like(src);
+    *out = h;
+    return BP_OK;
+}
+
+template <class C> static int prover_commit(bp_cs* h, bp_ctx* ctx, const uint64_t* v, const uint64_t* blind, size_t count, uint64_t* V_xy, bp_var* vars) {
+    host::ConstraintSystem<C>& cs = *h->cs<C>();
+    if (cs.phase2) return BP_E_ARG;
+    host::PedersenGens<C> pc = host::PedersenGens<C>::make_default();
+    if (ctx) pedersen_attach<C>(ctx, pc);
+    std::vector<A4> pts(count);
+    BPCHK(pc.commit_many((const F4*)v, (const F4*)blind, count, pts.data()));
+    for (size_t i = 0; i < count; i++) {   // Prover::commit (prover.rs:327-341), in order
+        const u32 idx = (u32)cs.v.size();
+        F4 a, b; memcpy(a.v, v + 4 * i, 32); memcpy(b.v, blind + 4 * i, 32);
+        cs.v.push_back(a); cs.v_blinding.push_back(b);
+        host::TP<C>::append_point(*cs.tr, "V", pts[i]);
+        h->commitments.push_back(pts[i]);
+        if (V_xy) memcpy(V_xy + 8 * i, &pts[i], 64);
+        if (vars) { vars[i].kind = BP_VAR_COMMITTED; vars[i].index = idx; }
+    }
+    return BP_OK;
+}
+template <class C> static int verifier_commit(bp_cs* h, const uint64_t* V_xy, size_t count, bp_var* vars) {
+    host::ConstraintSystem<C>& cs = *h->cs<C>();
+    if (cs.phase2) return BP_E_ARG;
+    for (size_t i = 0; i < count; i++) {   // Verifier::commit (verifier.rs:279-287)
+        A4 p; memcpy(&p, V_xy + 8 * i, 64);
+        const u32 idx = (u32)cs.V.size();
+        cs.V.push_back(p);
+        host::TP<C>::append_point(*cs.tr, "V", p);
+        h->commitments.push_back(p);
+        if (vars) { vars[i].kind = BP_VAR_COMMITTED; vars[i].index = idx; }
+    }
+    return BP_OK;
+}
+// a like-instance shares its source's phase-1 constraints: recording more of them there would fork the shared structure
+template <class C> static bool cs_can_record(bp_cs* h) { const auto& cs = *h->cs<C>(); return cs.phase2 || !cs.base; }
+
+template <class C> static int cs_multiply_t(bp_cs* h, const bp_var* lv, const uint64_t* lc, size_t nl, const bp_var* rv, const uint64_t* rc, size_t nr, bp_var out[3]) {
+    if (!terms_valid<C>(h, lv, nl) || !terms_valid<C>(h, rv, nr)) return BP_E_ARG;
+    std::vector<host::Term> l, r; terms_in(l, lv, lc, nl); terms_in(r, rv, rc, nr);
+    host::Var o[3];
+    h->cs<C>()->multiply(l.data(), nl, r.data(), nr, o);
+    for (int i = 0; i < 3; i++) out[i] = var_out(o[i]);
+    h->csc_tried = false; h->csc.reset();
+    return BP_OK;
+}
+template <class C> static int cs_allocate_t(bp_cs* h, const uint64_t* assignment, bp_var* out) {
+    F4 a; if (assignment) memcpy(a.v, assignment, 32);
+    host::Var o;
+    int rc = h->cs<C>()->allocate(assignment ? &a : nullptr, o);
+    if (rc) return rc;
+    *out = var_out(o);
+    return BP_OK;
+}
+template <class C> static int cs_allocate_multiplier_t(bp_cs* h, const uint64_t* l, const uint64_t* r, bp_var out[3]) {
+    F4 a, b; if (l) memcpy(a.v, l, 32); if (r) memcpy(b.v, r, 32);
+    host::Var o[3];
+    int rc = h->cs<C>()->allocate_multiplier(l ? &a : nullptr, r ? &b : nullptr, o);
+    if (rc) return rc;
+    for (int i = 0; i < 3; i++) out[i] = var_out(o[i]);
+    return BP_OK;
+}
+template <class C> static int cs_constrain_t(bp_cs* h, const bp_var* vars, const uint64_t* coefs, size_t n) {
+    if (!terms_valid<C>(h, vars, n)) return BP_E_ARG;
+    std::vector<host::Term> t; terms_in(t, vars, coefs, n);
+    h->cs<C>()->constrain(t.data(), n);
+    h->csc_tried = false; h->csc.reset();
+    return BP_OK;
+}
+// bulk forms: one call per gadget instead of one per gate
+template <class C> static int cs_allocate_multipliers_t(bp_cs* h, const uint64_t* l, const uint64_t* r, size_t count, uint32_t* first) {
+    host::ConstraintSystem<C>& cs = *h->cs<C>();
+    if (cs.proving && (!l || !r)) return BP_E_MISSING;
+    if (first) *first = (uint32_t)cs.num_vars;
+    cs.reserve(count, 0, 0);
+    for (size_t i = 0; i < count; i++) {
+        host::Var o[3];
+        if (cs.proving) { F4 a, b; memcpy(a.v, l + 4 * i, 32); memcpy(b.v, r + 4 * i, 32); cs.allocate_multiplier(&a, &b, o); }
+        else cs.allocate_multiplier(nullptr, nullptr, o);
+    }
+    return BP_OK;
+}
+template <class C> static int cs_constrain_many_t(bp_cs* h, const bp_var* vars, const uint64_t* coefs, const size_t* offsets, size_t nc) {
+    host::ConstraintSystem<C>& cs = *h->cs<C>();
+    const size_t nt = offsets[nc];
+    if (!terms_valid<C>(h, vars, nt)) return BP_E_ARG;
+    for (size_t q = 0; q < nc; q++) if (offsets[q] > offsets[q + 1]) return BP_E_ARG;
+    cs.reserve(0, nc, nt);
+    std::vector<host::Term> t; terms_in(t, vars, coefs, nt);
+    for (size_t q = 0; q < nc; q++) cs.constrain(t.data() + offsets[q], offsets[q + 1] - offsets[q]);
+    h->csc_tried = false; h->csc.reset();
+    return BP_OK;
+}
+template <class C> static int cs_specify_t(bp_cs* h, bp_randomize_cb cb, void* user) {
+    // the closure receives the handle the randomized phase runs on: the recorder passes itself, and a like-instance's copy of the
+    // closure must reach ITS handle — so the handle is found through the recorder, not captured
+    h->cs<C>()->specify_randomized_constraints([cb, user](host::ConstraintSystem<C>& cs) -> int { return cb(user, (bp_cs*)cs.owner); });
+    return BP_OK;
+}
+#define CS_RECORD_GUARD(h) do { if (!cs_live(h)) return BP_E_ARG; if (!CS_DISPATCH(h, cs_can_record<Secq>(h), cs_can_record<Zorro>(h))) { g_err = "this verifier shares its phase-1 constraints (bp_verifier_new_like): only commits and randomized constraints can be added"; return BP_E_ARG; } } while (0)
 
 // ---- C ABI ----------------------------------------------------------------------------------------
 extern "C" {
@@ -958,6 +1159,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
     for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); if (c->dec_ev[i]) (void)hipEventDestroy(c->dec_ev[i]); }
+    for (int i = 0; i < 2; i++) if (c->h_vaux[i]) (void)hipHostFree(c->h_vaux[i]);
     if (c->h_dec) (void)hipHostFree(c->h_dec);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     (void)hipStreamDestroy(c->stream);
@@ -1236,9 +1438,9 @@ int bp_r1cs_batch_verify_scenarios(bp_ctx* c, size_t count, const int* scenarios
 // ---- statements: Prover::new + commits + gadget, separated from prove() ----------------------------------
 int bp_stmt_prover_create(int curve, int scenario, const uint64_t* params, const uint8_t seed[32], bp_stmt** out) {
     if (!params || !seed || !out || (curve != 0 && curve != 1)) return BP_E_ARG;
-    bp_stmt* s = new bp_stmt(scenario, seed);
-    s->curve = curve;
-    int rc = curve == 0 ? stmt_build<Secq>(s, s->cs0, params) : stmt_build<Zorro>(s, s->cs1, params);
+    bp_stmt* s = new bp_stmt();
+    s->scenario = scenario;
+    int rc = curve == 0 ? stmt_build<Secq>(s, params, seed) : stmt_build<Zorro>(s, params, seed);
     if (rc) { delete s; return rc; }
     *out = s;
     return BP_OK;
@@ -1247,9 +1449,9 @@ int bp_stmt_prover_create(int curve, int scenario, const uint64_t* params, const
 int bp_stmt_prover_create_dev(bp_ctx* c, int scenario, const uint64_t* params, const uint8_t seed[32], bp_stmt** out) {
     if (!c || !params || !seed || !out) return BP_E_ARG;
     HIPCHK(hipSetDevice(c->device));
-    bp_stmt* s = new bp_stmt(scenario, seed);
-    s->curve = c->curve;
-    int rc = c->curve == 0 ? stmt_build<Secq>(s, s->cs0, params, c) : stmt_build<Zorro>(s, s->cs1, params, c);
+    bp_stmt* s = new bp_stmt();
+    s->scenario = scenario;
+    int rc = c->curve == 0 ? stmt_build<Secq>(s, params, seed, c) : stmt_build<Zorro>(s, params, seed, c);
     if (rc) { delete s; return rc; }
     *out = s;
     return BP_OK;
@@ -1266,52 +1468,161 @@ int bp_stmt_info(bp_stmt* s, uint64_t* commit_xy, size_t m_cap, size_t* m_out, u
     if (commit_xy) memcpy(commit_xy, s->io.commitments.data(), s->io.commitments.size() * 64);
     if (publics) memcpy(publics, s->io.publics.data(), s->io.publics.size() * 32);
     *m_out = s->io.commitments.size(); *npub = s->io.publics.size();
-    if (multipliers) *multipliers = s->curve == 0 ? s->cs0->num_vars : s->cs1->num_vars;
-    if (constraints) *constraints = s->curve == 0 ? s->cs0->num_constraints() : s->cs1->num_constraints();
+    if (multipliers) *multipliers = s->num_vars();
+    if (constraints) *constraints = s->num_constraints();
     return BP_OK;
 }
-int bp_stmt_prove(bp_ctx* c, bp_stmt* s, uint8_t* proof_out, size_t* proof_len, double* timing) {
-    if (!c || !s || !proof_out || !proof_len || s->curve != c->curve) return BP_E_ARG;
-    if (s->consumed) { g_err = "bp_stmt_prove: statement already consumed (Prover::prove takes self)"; return BP_E_ARG; }
-    HIPCHK(hipSetDevice(c->device));
-    if (!c->gens_cap) { g_err = "prove: generators not installed (bp_gens_derive / bp_gens_upload / bp_gens_share)"; return BP_E_GENS_LENGTH; }
-    s->consumed = true;
-    host::ProofData pf;
-    StageTimes tm;
-    int rc = c->curve == 0 ? r1cs_prove<Secq>(c, *s->cs0, s->prng, pf, tm, &s->pre0, s->csc.get()) : r1cs_prove<Zorro>(c, *s->cs1, s->prng, pf, tm, &s->pre1, s->csc.get());
-    if (rc) return rc;
-    std::vector<host::u8> bytes = c->curve == 0 ? host::proof_to_bytes<Secq>(pf) : host::proof_to_bytes<Zorro>(pf);
-    if (bytes.size() > *proof_len) { g_err = "prove: output buffer too small"; return BP_E_ARG; }
-    memcpy(proof_out, bytes.data(), bytes.size()); *proof_len = bytes.size();
-    if (timing) { timing[0] = tm.total; timing[1] = 0; timing[2] = tm.rng; timing[3] = tm.upload; timing[4] = tm.commit_msm; timing[5] = tm.flatten; timing[6] = tm.poly; timing[7] = tm.ipa; }
+bp_cs* bp_stmt_as_prover(bp_stmt* s) { return s; }
+int bp_stmt_prove(bp_ctx* c, bp_stmt* s, uint8_t* proof_out, size_t* proof_len, double* timing) { return bp_prover_prove(c, s, nullptr, proof_out, proof_len, timing); }
+int bp_stmt_precompute(bp_stmt* s) { return bp_prover_precompute(s, nullptr); }
+int bp_stmt_precompute_batch(bp_stmt** stmts, size_t count) { return bp_prover_precompute_batch((bp_cs**)stmts, count); }
+
+
+int bp_prover_new(int curve, void* transcript, bp_cs** out) {
+    if (!transcript || !out || (curve != 0 && curve != 1)) return BP_E_ARG;
+    bp_cs* h = new bp_cs();
+    if (curve == 0) cs_handle_init<Secq>(h, true, (host::Transcript*)transcript); else cs_handle_init<Zorro>(h, true, (host::Transcript*)transcript);
+    *out = h;
     return BP_OK;
 }
-// host-only head of prove(): `m`, TranscriptRng, phase-1 blinding draws (the sequential Keccak chain); idempotent
-int bp_stmt_precompute(bp_stmt* s) {
-    if (!s || s->consumed) return BP_E_ARG;
-    if (s->curve == 0) { if (!s->pre0.rng) prove_precompute<Secq>(*s->cs0, s->prng, s->pre0); }
-    else { if (!s->pre1.rng) prove_precompute<Zorro>(*s->cs1, s->prng, s->pre1); }
+int bp_verifier_new(int curve, void* transcript, bp_cs** out) {
+    if (!transcript || !out || (curve != 0 && curve != 1)) return BP_E_ARG;
+    bp_cs* h = new bp_cs();
+    if (curve == 0) cs_handle_init<Secq>(h, false, (host::Transcript*)transcript); else cs_handle_init<Zorro>(h, false, (host::Transcript*)transcript);
+    *out = h;
+    return BP_OK;
+}
+int bp_verifier_new_like(bp_cs* of, void* transcript, bp_cs** out) {
+    if (!cs_live(of) || of->proving || !transcript || !out) { g_err = "bp_verifier_new_like: needs a live verifier handle"; return BP_E_ARG; }
+    return CS_DISPATCH(of, verifier_new_like<Secq>(of, (host::Transcript*)transcript, out), verifier_new_like<Zorro>(of, (host::Transcript*)transcript, out));
+}
+void bp_cs_free(bp_cs* h) { delete h; }
+void* bp_cs_transcript(bp_cs* h) { return h ? h->tr : nullptr; }
+int bp_cs_metrics(bp_cs* h, size_t* multipliers, size_t* constraints, size_t* commitments) {
+    if (!h) return BP_E_ARG;
+    if (multipliers) *multipliers = h->num_vars();
+    if (constraints) *constraints = h->num_constraints();
+    if (commitments) *commitments = h->commitments.size();
+    return BP_OK;
+}
+int bp_prover_commit(bp_cs* h, bp_ctx* ctx, const uint64_t* v, const uint64_t* v_blinding, size_t count, uint64_t* V_xy_out, bp_var* vars_out) {
+    if (!cs_live(h) || !h->proving || (count && (!v || !v_blinding))) return BP_E_ARG;
+    if (ctx) { if (ctx->curve != h->curve) return BP_E_ARG; HIPCHK(hipSetDevice(ctx->device)); }
+    return CS_DISPATCH(h, prover_commit<Secq>(h, ctx, v, v_blinding, count, V_xy_out, vars_out), prover_commit<Zorro>(h, ctx, v, v_blinding, count, V_xy_out, vars_out));
+}
+int bp_verifier_commit(bp_cs* h, const uint64_t* V_xy, size_t count, bp_var* vars_out) {
+    if (!cs_live(h) || h->proving || (count && !V_xy)) return BP_E_ARG;
+    return CS_DISPATCH(h, verifier_commit<Secq>(h, V_xy, count, vars_out), verifier_commit<Zorro>(h, V_xy, count, vars_out));
+}
+int bp_cs_multiply(bp_cs* h, const bp_var* lv, const uint64_t* lc, size_t nl, const bp_var* rv, const uint64_t* rc, size_t nr, bp_var out[3]) {
+    CS_RECORD_GUARD(h);
+    if (!out || (nl && (!lv || !lc)) || (nr && (!rv || !rc))) return BP_E_ARG;
+    return CS_DISPATCH(h, cs_multiply_t<Secq>(h, lv, lc, nl, rv, rc, nr, out), cs_multiply_t<Zorro>(h, lv, lc, nl, rv, rc, nr, out));
+}
+int bp_cs_allocate(bp_cs* h, const uint64_t* assignment, bp_var* out) {
+    CS_RECORD_GUARD(h);
+    if (!out) return BP_E_ARG;
+    return CS_DISPATCH(h, cs_allocate_t<Secq>(h, assignment, out), cs_allocate_t<Zorro>(h, assignment, out));
+}
+int bp_cs_allocate_multiplier(bp_cs* h, const uint64_t* left, const uint64_t* right, bp_var out[3]) {
+    CS_RECORD_GUARD(h);
+    if (!out) return BP_E_ARG;
+    return CS_DISPATCH(h, cs_allocate_multiplier_t<Secq>(h, left, right, out), cs_allocate_multiplier_t<Zorro>(h, left, right, out));
+}
+int bp_cs_constrain(bp_cs* h, const bp_var* vars, const uint64_t* coefs, size_t n) {
+    CS_RECORD_GUARD(h);
+    if (n && (!vars || !coefs)) return BP_E_ARG;
+    return CS_DISPATCH(h, cs_constrain_t<Secq>(h, vars, coefs, n), cs_constrain_t<Zorro>(h, vars, coefs, n));
+}
+int bp_cs_allocate_multipliers(bp_cs* h, const uint64_t* left, const uint64_t* right, size_t count, uint32_t* first_index) {
+    CS_RECORD_GUARD(h);
+    return CS_DISPATCH(h, cs_allocate_multipliers_t<Secq>(h, left, right, count, first_index), cs_allocate_multipliers_t<Zorro>(h, left, right, count, first_index));
+}
+int bp_cs_constrain_many(bp_cs* h, const bp_var* vars, const uint64_t* coefs, const size_t* offsets, size_t nconstraints) {
+    CS_RECORD_GUARD(h);
+    if (!offsets || (offsets[nconstraints] && (!vars || !coefs))) return BP_E_ARG;
+    return CS_DISPATCH(h, cs_constrain_many_t<Secq>(h, vars, coefs, offsets, nconstraints), cs_constrain_many_t<Zorro>(h, vars, coefs, offsets, nconstraints));
+}
+int bp_cs_specify_randomized_constraints(bp_cs* h, bp_randomize_cb cb, void* user) {
+    if (!cs_live(h) || !cb) return BP_E_ARG;
+    if (CS_DISPATCH(h, h->cs0->phase2, h->cs1->phase2)) { g_err = "specify_randomized_constraints inside the randomized phase"; return BP_E_ARG; }
+    CS_RECORD_GUARD(h);
+    return CS_DISPATCH(h, cs_specify_t<Secq>(h, cb, user), cs_specify_t<Zorro>(h, cb, user));
+}
+int bp_cs_challenge_scalar(bp_cs* h, const char* label, uint64_t out[4]) {
+    if (!cs_live(h) || !label || !out) return BP_E_ARG;
+    if (!CS_DISPATCH(h, h->cs0->phase2, h->cs1->phase2)) { g_err = "challenge_scalar is only available to randomized constraints (RandomizedConstraintSystem)"; return BP_E_ARG; }
+    F4 r = CS_DISPATCH(h, h->cs0->challenge_scalar(label), h->cs1->challenge_scalar(label));
+    memcpy(out, r.v, 32);
+    return BP_OK;
+}
+int bp_prover_precompute(bp_cs* h, const uint8_t rng_bytes[32]) {
+    if (!cs_live(h) || !h->proving) return BP_E_ARG;
+    if (rng_bytes) { memcpy(h->rng32, rng_bytes, 32); h->have_rng = true; }
+    if (!h->have_rng) { g_err = "prove: the external rng bytes are missing"; return BP_E_ARG; }
+    if (h->curve == 0) { if (!h->pre0.rng) prove_precompute<Secq>(*h->cs0, h->rng32, h->pre0); }
+    else { if (!h->pre1.rng) prove_precompute<Zorro>(*h->cs1, h->rng32, h->pre1); }
     return BP_OK;
 }
 // the same for a batch: groups of 8 same-shaped statements share one AVX-512 Keccak-f x8 stream; others go one by one
-int bp_stmt_precompute_batch(bp_stmt** stmts, size_t count) {
-    if (!stmts) return BP_E_ARG;
-    for (size_t i = 0; i < count; i++) if (!stmts[i] || stmts[i]->consumed || stmts[i]->curve != stmts[0]->curve) return BP_E_ARG;
-    for (size_t g = 0; g < count; g += 8) {
-        const size_t c = std::min<size_t>(8, count - g);
-        host::ChaChaRng* prngs[8];
-        if (stmts[0]->curve == 0) {
-            host::ConstraintSystem<Secq>* css[8]; ProvePre<Secq>* pres[8];
-            for (size_t j = 0; j < c; j++) { css[j] = stmts[g + j]->cs0.get(); prngs[j] = &stmts[g + j]->prng; pres[j] = &stmts[g + j]->pre0; }
-            prove_precompute_batch<Secq>(css, prngs, pres, c);
-        } else {
-            host::ConstraintSystem<Zorro>* css[8]; ProvePre<Zorro>* pres[8];
-            for (size_t j = 0; j < c; j++) { css[j] = stmts[g + j]->cs1.get(); prngs[j] = &stmts[g + j]->prng; pres[j] = &stmts[g + j]->pre1; }
-            prove_precompute_batch<Zorro>(css, prngs, pres, c);
-        }
-    }
+int bp_prover_precompute_batch(bp_cs** hs, size_t count) {
+    if (!hs) return BP_E_ARG;
+    for (size_t i = 0; i < count; i++) if (!cs_live(hs[i]) || !hs[i]->proving || !hs[i]->have_rng || hs[i]->curve != hs[0]->curve) return BP_E_ARG;
+    if (!count) return BP_OK;
+    return hs[0]->curve == 0 ? cs_precompute_batch<Secq>(hs, count) : cs_precompute_batch<Zorro>(hs, count);
+}
+int bp_prover_set_rng(bp_cs* h, const uint8_t rng_bytes[32]) {
+    if (!cs_live(h) || !h->proving || !rng_bytes) return BP_E_ARG;
+    memcpy(h->rng32, rng_bytes, 32); h->have_rng = true;
     return BP_OK;
 }
+int bp_prover_prove(bp_ctx* c, bp_cs* h, const uint8_t rng_bytes[32], uint8_t* proof_out, size_t* proof_len, double* timing) {
+    if (!c || !h || !h->proving || !proof_out || !proof_len || h->curve != c->curve) return BP_E_ARG;
+    if (h->consumed) { g_err = "prove: the prover was already consumed (Prover::prove takes self)"; return BP_E_ARG; }
+    if (rng_bytes) {
+        if (h->have_rng && (h->pre0.rng || h->pre1.rng) && memcmp(h->rng32, rng_bytes, 32)) { g_err = "prove: rng bytes differ from the precomputed ones"; return BP_E_ARG; }
+        memcpy(h->rng32, rng_bytes, 32); h->have_rng = true;
+    }
+    if (!h->have_rng) { g_err = "prove: the external rng bytes are missing"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->gens_cap) { g_err = "prove: generators not installed (bp_gens_derive / bp_gens_upload / bp_gens_share)"; return BP_E_GENS_LENGTH; }
+    h->consumed = true; h->running = true;
+    const int rc = c->curve == 0 ? cs_prove<Secq>(c, h, proof_out, proof_len, timing) : cs_prove<Zorro>(c, h, proof_out, proof_len, timing);
+    h->running = false;
+    return rc;
+}
+int bp_r1cs_batch_verify(bp_ctx* c, size_t count, bp_cs* const* verifiers, const uint8_t* proofs, const size_t* proof_lens, const uint64_t* alphas, double* timing,
+                         uint64_t* check_point_xy) {
+    if (!c) return BP_E_ARG;
+    if (count == 0) { if (check_point_xy) memset(check_point_xy, 0, 64); return BP_OK; }   // the reference's mega-check of nothing is the identity (verifier.rs:685-690)
+    if (!verifiers || !proofs || !proof_lens) return BP_E_ARG;
+    for (size_t k = 0; k < count; k++) {
+        if (!verifiers[k] || verifiers[k]->consumed || verifiers[k]->proving || verifiers[k]->curve != c->curve) { g_err = "batch_verify: every instance needs a live verifier of the ctx's curve"; return BP_E_ARG; }
+        for (size_t j = 0; j < k && count <= 4096; j++) if (verifiers[j] == verifiers[k]) { g_err = "batch_verify: a verifier is consumed by ONE instance"; return BP_E_ARG; }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; return BP_E_GENS_LENGTH; }
+    return c->curve == 0 ? cs_batch_verify<Secq>(c, count, verifiers, proofs, proof_lens, alphas, timing, check_point_xy)
+                         : cs_batch_verify<Zorro>(c, count, verifiers, proofs, proof_lens, alphas, timing, check_point_xy);
+}
+int bp_verifier_verify(bp_ctx* c, bp_cs* v, const uint8_t* proof, size_t proof_len) {
+    return bp_r1cs_batch_verify(c, 1, &v, proof, &proof_len, nullptr, nullptr, nullptr);
+}
+// merlin::Transcript state for hosts that keep their own merlin: 200 bytes of Keccak state, then pos, pos_begin, cur_flags
+int bp_transcript_export_state(const void* t, uint8_t out[203]) {
+    if (!t || !out) return BP_E_ARG;
+    const host::Transcript* tr = (const host::Transcript*)t;
+    memcpy(out, tr->s.st.b, 200); out[200] = tr->s.pos; out[201] = tr->s.pos_begin; out[202] = tr->s.cur;
+    return BP_OK;
+}
+int bp_transcript_import_state(void* t, const uint8_t in[203]) {
+    if (!t || !in || in[200] >= host::Strobe::RATE || in[201] > host::Strobe::RATE) return BP_E_ARG;
+    host::Transcript* tr = (host::Transcript*)t;
+    memcpy(tr->s.st.b, in, 200); tr->s.pos = in[200]; tr->s.pos_begin = in[201]; tr->s.cur = in[202];
+    return BP_OK;
+}
+void* bp_transcript_clone(const void* t) { return t ? new host::Transcript(*(const host::Transcript*)t) : nullptr; }
+
 // dst uses src's resident generator tables (same device, same curve) without copying; src must outlive dst
 int bp_gens_share(bp_ctx* dst, bp_ctx* src) {
     if (!dst || !src || dst == src || dst->curve != src->curve || dst->device != src->device || !src->gens_cap) return BP_E_ARG;

@@ -126,7 +126,8 @@ struct TranscriptRng {
         u32 len = (u32)n;
         s.meta_ad((const u8*)label, strlen(label), false); s.meta_ad((const u8*)&len, 4, true); s.key(w, n, false);
     }
-    template <class R> void finalize(R& ext) { u8 b[32]; ext.fill_bytes(b, 32); s.meta_ad((const u8*)"rng", 3, false); s.key(b, 32, false); }
+    void finalize_bytes(const u8 b[32]) { s.meta_ad((const u8*)"rng", 3, false); s.key(b, 32, false); }
+    template <class R> void finalize(R& ext) { u8 b[32]; ext.fill_bytes(b, 32); finalize_bytes(b); }
     // fill_bytes(8).  Steady state (pos = 8, pos_begin = 0, i.e. right after a previous 8-byte draw): the six STROBE steps
     // meta_ad(LE32(8)) ; prf(8) collapse to three constant XORs, one permutation and reading lane 0.
     inline u64 next_u64() {
@@ -287,16 +288,86 @@ static inline const char* scenario_label(int sc) {
     }
 }
 
+// ---- canonical structure of a recording ---------------------------------------------------------------------
+// Two verifier instances of one gadget record the same constraint STRUCTURE (which variable appears in which constraint) but
+// may differ in coefficient VALUES: a public input enters as a constant, a randomized (phase-2) constraint carries the
+// instance's own challenge (benches/r1cs_secq256k1.rs:47-52: `x - z`).  CanonState walks a recording in order and numbers the
+// distinct coefficient values by first occurrence (+1 and -1 are flags, not numbers): instances of one gadget then produce the
+// same id sequence — hence the same 128-bit structure digest — and a small per-instance table id -> value.  The GPU-resident
+// constraint matrices ("templates", r1cs_host.inc) are keyed by the digest and evaluated with the instance's table.
+static constexpr u32 CID_ONE = 0x80000000u, CID_MONE = 0x40000000u, CID_MASK = 0x3fffffffu;
+struct Digest {
+    u64 a = 0, b = 0;
+    bool operator==(const Digest& o) const { return a == o.a && b == o.b; }
+    bool operator<(const Digest& o) const { return a != o.a ? a < o.a : b < o.b; }
+};
+struct CanonState {
+    u64 ha = 0x9E3779B97F4A7C15ULL, hb = 0xC2B2AE3D27D4EB4FULL;
+    std::vector<F4> coefs;      // id -> value
+    std::vector<u32> slots;     // open addressing over coefs (power-of-two size, 0xFFFFFFFF = empty)
+    inline void mix(u64 x) {
+        ha = (ha ^ x) * 0xFF51AFD7ED558CCDULL; ha ^= ha >> 32;
+        hb = (hb + x) * 0x9FB21C651E98DF25ULL; hb = (hb << 27) | (hb >> 37);
+    }
+    static inline u64 hash_fe(const F4& c) { u64 h = c.v[0] * 0x9E3779B97F4A7C15ULL ^ c.v[1] * 0xC2B2AE3D27D4EB4FULL ^ c.v[2] * 0x165667B19E3779F9ULL ^ c.v[3]; return h ^ (h >> 29); }
+    void grow() {
+        const size_t nsz = slots.empty() ? 64 : slots.size() * 2;
+        slots.assign(nsz, 0xFFFFFFFFu);
+        for (u32 id = 0; id < coefs.size(); id++) { size_t p = hash_fe(coefs[id]) & (nsz - 1); while (slots[p] != 0xFFFFFFFFu) p = (p + 1) & (nsz - 1); slots[p] = id; }
+    }
+    inline u32 id_of(const F4& c) {
+        if (coefs.size() * 2 >= slots.size()) grow();
+        size_t p = hash_fe(c) & (slots.size() - 1);
+        for (;;) {
+            const u32 id = slots[p];
+            if (id == 0xFFFFFFFFu) { slots[p] = (u32)coefs.size(); coefs.push_back(c); return (u32)coefs.size() - 1; }
+            if (coefs[id] == c) return id;
+            p = (p + 1) & (slots.size() - 1);
+        }
+    }
+    inline u32 classify(const F4& c, const F4& one, const F4& mone) { return c == one ? CID_ONE : c == mone ? CID_MONE : id_of(c); }
+    // fn(q, term, cid) for every term of constraints [0, nq) of (terms, off), numbered q0 + local index
+    template <class Fn> void walk(const Term* terms, const size_t* off, size_t nq, size_t q0, const F4& one, const F4& mone, Fn&& fn) {
+        for (size_t q = 0; q < nq; q++) {
+            mix(0xC0000000ULL + (off[q + 1] - off[q]));
+            for (size_t k = off[q]; k < off[q + 1]; k++) {
+                const Term& t = terms[k];
+                const u32 cid = classify(t.c, one, mone);
+                mix(((u64)t.v.k << 32) | t.v.i); mix(cid);
+                fn(q0 + q, t, cid);
+            }
+        }
+    }
+    Digest digest(size_t n1, size_t n, size_t nq) const { CanonState t; t.ha = ha; t.hb = hb; t.mix(n1); t.mix(n); t.mix(nq); t.mix(coefs.size()); Digest d; d.a = t.ha; d.b = t.hb; return d; }
+};
+struct VTerm { u32 j, q; F4 c; };   // committed variable j in constraint q with coefficient c: feeds wV (verifier.rs:334-338, prover.rs:385-387)
+
+// A phase-1 recording that several verifier instances share (bp_verifier_new_like): immutable once frozen.
+struct FrozenRecording {
+    std::vector<Term> terms;
+    std::vector<size_t> off{0};
+    size_t num_vars = 0;
+    bool has_pending = false; size_t pending = 0;
+    CanonState canon;              // state after walking every constraint of this part
+    std::vector<VTerm> vterms;     // in constraint order
+    size_t nq() const { return off.size() - 1; }
+};
+
 // The recorder shared by prover and verifier: the verifier records the same constraints without
 // assignments.  Constraints are stored flat (CSR-like) because circuits reach 2^22 multipliers.
 template <class C> struct ConstraintSystem {
     typedef Fld<typename C::Fr> S;
     Transcript* tr = nullptr;
     bool proving = false;
-    // flat constraint storage: constraint q owns terms [cs_off[q], cs_off[q+1])
+    void* owner = nullptr;         // the C-ABI handle that wraps this recorder (randomized closures of a C caller receive it)
+    // an optional shared phase-1 part (constraints [0, base->nq()), multipliers [0, base->num_vars)); what this instance records
+    // itself follows: constraint base->nq() + q owns terms [cs_off[q], cs_off[q+1])
+    std::shared_ptr<const FrozenRecording> base;
     std::vector<Term> cs_terms;
     std::vector<size_t> cs_off{0};
-    size_t num_vars = 0;
+    size_t num_vars = 0;           // all multipliers, the base's included
+    size_t n1 = 0;                 // multipliers allocated before the randomized phase (set by run_randomized)
+    bool phase2 = false;
     bool has_pending = false; size_t pending = 0;
     std::vector<std::function<int(ConstraintSystem&)>> deferred;
     // prover secrets
@@ -375,35 +446,72 @@ template <class C> struct ConstraintSystem {
     // create_randomized_constraints (prover.rs:418-441 / verifier.rs:353-376)
     int run_randomized() {
         has_pending = false;
+        n1 = num_vars; phase2 = true;
         if (deferred.empty()) { TP<C>::r1cs_1phase_domain_sep(*tr); return BP_OK; }
         TP<C>::r1cs_2phase_domain_sep(*tr);
         std::vector<std::function<int(ConstraintSystem&)>> cbs; cbs.swap(deferred);
         for (auto& cb : cbs) { int rc = cb(*this); if (rc) return rc; }
         return BP_OK;
     }
-    size_t num_constraints() const { return cs_off.size() - 1; }
+    size_t base_nq() const { return base ? base->nq() : 0; }
+    size_t num_constraints() const { return base_nq() + cs_off.size() - 1; }
+    size_t num_terms() const { return (base ? base->terms.size() : 0) + cs_terms.size(); }
+    // fn(q, term) over every recorded term, the shared part first
+    template <class Fn> void for_each_term(Fn&& fn) const {
+        if (base) for (size_t q = 0; q < base->nq(); q++) for (size_t k = base->off[q]; k < base->off[q + 1]; k++) fn(q, base->terms[k]);
+        const size_t q0 = base_nq();
+        for (size_t q = 0; q + 1 < cs_off.size(); q++) for (size_t k = cs_off[q]; k < cs_off[q + 1]; k++) fn(q0 + q, cs_terms[k]);
+    }
+    // Freezes what has been recorded so far (phase 1) into a shareable part; this instance continues on top of it.
+    int freeze() {
+        if (phase2 || proving) return BP_E_ARG;
+        if (base && cs_terms.empty() && cs_off.size() == 1 && num_vars == base->num_vars) return BP_OK;   // already frozen, nothing new
+        if (base) return BP_E_ARG;                         // (a second layer is not needed: like-instances record nothing in phase 1)
+        auto f = std::make_shared<FrozenRecording>();
+        f->terms.swap(cs_terms); f->off.swap(cs_off); f->num_vars = num_vars; f->has_pending = has_pending; f->pending = pending;
+        cs_off.assign(1, 0);
+        const F4 one = S::one(), mone = S::neg(S::one());
+        f->canon.walk(f->terms.data(), f->off.data(), f->nq(), 0, one, mone, [&](size_t q, const Term& t, u32) {
+            if (t.v.k == VK_COMMITTED) f->vterms.push_back(VTerm{t.v.i, (u32)q, t.c});
+        });
+        base = f;
+        return BP_OK;
+    }
+    // a fresh verifier instance of the same gadget: shares `src`'s frozen phase-1 recording and its deferred closures
+    void init_like(const ConstraintSystem& src) {
+        base = src.base; num_vars = src.num_vars; has_pending = src.has_pending; pending = src.pending; deferred = src.deferred; proving = false;
+    }
+    // Canonical form of the whole recording (shared part + own part).  st_own is scratch for instances that recorded something
+    // themselves; the returned state is the base's cached one otherwise (no copy).  own_vterms: committed-variable terms of the own part.
+    const CanonState& canonical(CanonState& st_own, std::vector<VTerm>* own_vterms) const {
+        const bool own_empty = cs_off.size() == 1;
+        if (base && own_empty) return base->canon;
+        if (base) st_own = base->canon; else st_own = CanonState();
+        const F4 one = S::one(), mone = S::neg(S::one());
+        st_own.walk(cs_terms.data(), cs_off.data(), cs_off.size() - 1, base_nq(), one, mone, [&](size_t q, const Term& t, u32) {
+            if (own_vterms && t.v.k == VK_COMMITTED) own_vterms->push_back(VTerm{t.v.i, (u32)q, t.c});
+        });
+        return st_own;
+    }
     // flattened_constraints (prover.rs:354-397 / verifier.rs:304-349): w* = sum_q z^(q+1) * W*[q, .]
     void flatten(const F4& z, std::vector<F4>& wL, std::vector<F4>& wR, std::vector<F4>& wO, std::vector<F4>& wV, F4& wc, size_t m) const {
         size_t n = num_vars;
         wL.assign(n, S::zero()); wR.assign(n, S::zero()); wO.assign(n, S::zero()); wV.assign(m, S::zero()); wc = S::zero();
-        F4 ez = z;
+        F4 ez = z, nez = S::neg(z);
+        size_t cur_q = 0;
         const F4 one = S::one(), minus_one = S::neg(S::one());
-        for (size_t q = 0; q + 1 < cs_off.size(); q++) {
-            const F4 nez = S::neg(ez);
-            for (size_t k = cs_off[q]; k < cs_off[q + 1]; k++) {
-                const Term& t = cs_terms[k];
-                // most coefficients of real circuits are +-1: no multiplication needed for those
-                F4 p = t.c == one ? ez : t.c == minus_one ? nez : S::mul(ez, t.c);
-                switch (t.v.k) {
-                    case VK_LEFT: wL[t.v.i] = S::add(wL[t.v.i], p); break;
-                    case VK_RIGHT: wR[t.v.i] = S::add(wR[t.v.i], p); break;
-                    case VK_OUT: wO[t.v.i] = S::add(wO[t.v.i], p); break;
-                    case VK_COMMITTED: wV[t.v.i] = S::sub(wV[t.v.i], p); break;
-                    default: wc = S::sub(wc, p); break;
-                }
+        for_each_term([&](size_t q, const Term& t) {
+            while (cur_q < q) { ez = S::mul(ez, z); cur_q++; nez = S::neg(ez); }
+            // most coefficients of real circuits are +-1: no multiplication needed for those
+            F4 p = t.c == one ? ez : t.c == minus_one ? nez : S::mul(ez, t.c);
+            switch (t.v.k) {
+                case VK_LEFT: wL[t.v.i] = S::add(wL[t.v.i], p); break;
+                case VK_RIGHT: wR[t.v.i] = S::add(wR[t.v.i], p); break;
+                case VK_OUT: wO[t.v.i] = S::add(wO[t.v.i], p); break;
+                case VK_COMMITTED: wV[t.v.i] = S::sub(wV[t.v.i], p); break;
+                default: wc = S::sub(wc, p); break;
             }
-            ez = S::mul(ez, z);
-        }
+        });
     }
 };
 

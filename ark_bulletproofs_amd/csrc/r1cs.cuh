@@ -181,12 +181,12 @@ static constexpr u32 VFY_PB_SCALARS = VFY_PB_WORDS / 8;
 // [s_lo | s_hi | r_lo | r_hi | y_lo | y_hi | z_lo (256) | z_hi (nzhi)], stride 3 * (2^LOB + 2^HIB) + 256 + nzhi.
 // grid (ceil(max(2^LOB, 2^HIB, 256, nzhi) / 256), P).
 template <class C> __global__ void __launch_bounds__(256)
-k_vfy_tables(const u32* __restrict__ params, u32 P, u32 k, u32 LOB, u32 nzhi, u32* __restrict__ tables) {
+k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P, u32 k, u32 LOB, u32 nzhi, u32* __restrict__ tables) {
     typedef typename C::Fr F;
     const u32 tIdx = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
     if (p >= P) return;
     const u32 HIB = k - LOB, nlo = 1u << LOB, nhi = 1u << HIB;
-    const u32* pb = params + (size_t)p * VFY_PB_WORDS;
+    const u32* pb = params + (size_t)perm[p] * VFY_PB_WORDS;   // perm: the group's proofs as positions in the block's parameter array
     const u32* ztab = pb;
     const u32* ytab = pb + 256;
     const u32* cst = pb + 512;
@@ -219,7 +219,8 @@ k_vfy_tables(const u32* __restrict__ params, u32 P, u32 k, u32 LOB, u32 nzhi, u3
 
 // grid (ceil(N/256), nchunks).  g_part/h_part: [nchunks][N] resident words; d_part: [nchunks * gridDim.x] resident words.
 template <class C> __global__ void __launch_bounds__(256)
-k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chunk, u32 n, u32 N, u32 k, u32* __restrict__ g_part,
+k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restrict__ perm, const u32* __restrict__ coef_tabs, u32 coef_stride,
+            u32 P, u32 per_chunk, u32 n, u32 n1, u32 N, u32 k, u32* __restrict__ g_part,
             u32* __restrict__ h_part, u32* __restrict__ d_part, const u32* __restrict__ tables, u32 LOB, u32 nzhi) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
@@ -229,11 +230,14 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chu
     Fe ag = fe_zero<F>(), ah = fe_zero<F>(), ad = fe_zero<F>();
     if (i < N) {
         for (u32 p = p0; p < p1; p++) {
-            const u32* pb = params + (size_t)p * VFY_PB_WORDS;
+            const u32* pb = params + (size_t)perm[p] * VFY_PB_WORDS;
             const u32* ztab = pb;
             const u32* ytab = pb + 256;
             const u32* cst = pb + 512;
             const u32* usq = pb + 576;
+            // coefficient values: the template's own table, or this proof's (instances of one gadget differ in public constants
+            // and in the challenges their randomized constraints carry)
+            const u32* coefs = coef_tabs ? coef_tabs + (size_t)p * coef_stride : t.coefs;
             const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
             const Fe alpha = load_fe_dev<F>(cst + 40);
             const u32 nlo = 1u << LOB, nhi = 1u << (k - LOB), lo = i & (nlo - 1u), hi = i >> LOB;
@@ -257,7 +261,7 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chu
                     Fe term;
                     if (cid & 0x80000000u) term = zp;
                     else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zp));
-                    else term = fe_mul<F>(zp, load_fe_dev<F>(t.coefs + (size_t)cid * 8));
+                    else term = fe_mul<F>(zp, load_fe_dev<F>(coefs + (size_t)cid * 8));
                     if (vec == 0) wL = fe_addr<F>(wL, term); else if (vec == 1) wR = fe_addr<F>(wR, term); else wO = fe_addr<F>(wO, term);
                 }
                 const Fe ywR = fe_mul<F>(yni, wR);
@@ -270,8 +274,8 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chu
                 g = fe_neg<F, 2>(fe_mul<F>(a, s_i));
                 h = fe_sub<F, 2>(fe_mul<F>(yni, fe_neg<F, 2>(fe_mul<F>(b, s_rev))), fe_one<F>());
             }
-            // single-phase statements: n1 = n, so u_or_1 = 1 for i < n and u on the padding (verifier.rs:486-489)
-            if (i >= n) {
+            // u_or_1 = 1 for the phase-1 multipliers, u for the randomized-phase ones and on the padding (verifier.rs:486-489)
+            if (i >= n1) {
                 const Fe u = load_fe_dev<F>(cst + 32);
                 g = fe_mul<F>(g, u);
                 h = fe_mul<F>(h, u);
@@ -280,8 +284,12 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, u32 P, u32 per_chu
             ah = fe_addr<F>(ah, fe_mul<F>(alpha, h));
             // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms
             Fe wcp = fe_zero<F>();
-            for (u32 e = i; e < t.n_const; e += N)
-                wcp = fe_addr<F>(wcp, fe_mul<F>(pow_table<F>(ztab, t.const_q[e] + 1), load_fe_dev<F>(t.coefs + (size_t)t.const_c[e] * 8)));   // (a handful of terms per circuit)
+            for (u32 e = i; e < t.n_const; e += N) {   // (lanes share the constant terms; a handful per circuit, or one per gate)
+                const u32 cid = t.const_c[e];
+                const Fe zq = pow_table<F>(ztab, t.const_q[e] + 1);
+                const Fe term = (cid & 0x80000000u) ? zq : (cid & 0x40000000u) ? fe_wred<F>(fe_neg<F, 2>(zq)) : fe_mul<F>(zq, load_fe_dev<F>(coefs + (size_t)cid * 8));
+                wcp = fe_addr<F>(wcp, term);
+            }
             if (t.n_const > i) ad = fe_addr<F>(ad, fe_neg<F, 4>(fe_mul<F>(load_fe_dev<F>(cst + 48), wcp)));
         }
         store_fe_dev<F>(g_part + ((size_t)chunk * N + i) * 8, ag);

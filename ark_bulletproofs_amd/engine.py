@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check, lib, ptr, u64arr
+from ._lib import ArkbpError, check, lib, ptr, u64arr  # noqa: F401
 
 SECQ256K1, ZORRO = 0, 1
 
@@ -546,3 +546,203 @@ def _debug_decompress(self, compressed):
 
 
 Engine.debug_decompress = _debug_decompress
+
+
+# ---- r1cs::ConstraintSystem / Prover / Verifier for the caller's own gadgets (include/arkbp.h "bp_cs") ----------------------
+# Variables are (kind, index) pairs; a linear combination is a list of (variable, coefficient) with coefficients as 4 x u64
+# Montgomery words — the shapes the reference's `Variable` and `LinearCombination` have (src/r1cs/linear_combination.rs).
+VAR_COMMITTED, VAR_MULT_LEFT, VAR_MULT_RIGHT, VAR_MULT_OUT, VAR_ONE = 0, 1, 2, 3, 4
+ONE_VAR = (VAR_ONE, 0)
+_RANDOMIZE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+def _lc_arrays(lc):
+    n = len(lc)
+    vars_ = np.zeros((max(n, 1), 2), dtype=np.uint32)
+    coefs = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    for i, (v, c) in enumerate(lc):
+        vars_[i] = v
+        coefs[i] = np.asarray(c, dtype=np.uint64).reshape(4)
+    return vars_, coefs, n
+
+
+def _vars_out(arr):
+    return [(int(arr[i, 0]), int(arr[i, 1])) for i in range(len(arr))]
+
+
+class _ConstraintSystem:
+    """What `impl ConstraintSystem for Prover / Verifier` offers (src/r1cs/constraint_system.rs:19-135), over a bp_cs handle."""
+
+    def __init__(self, curve, transcript, handle=None):
+        self.curve, self.transcript_obj = curve, transcript   # the transcript is borrowed: keep it alive
+        self.h = handle if handle is not None else C.c_void_p()
+        self._cbs = []
+        self._cb_errors = []
+
+    def free(self):
+        if self.h:
+            lib().bp_cs_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def transcript(self):
+        return self.transcript_obj
+
+    def multiply(self, left, right):
+        lv, lc, nl = _lc_arrays(left)
+        rv, rc, nr = _lc_arrays(right)
+        out = np.zeros((3, 2), dtype=np.uint32)
+        check(lib().bp_cs_multiply(self.h, ptr(lv), ptr(lc), C.c_size_t(nl), ptr(rv), ptr(rc), C.c_size_t(nr), ptr(out)), "bp_cs_multiply")
+        return _vars_out(out)
+
+    def allocate(self, assignment=None):
+        out = np.zeros((1, 2), dtype=np.uint32)
+        a = None if assignment is None else np.ascontiguousarray(assignment, dtype=np.uint64).reshape(4)
+        check(lib().bp_cs_allocate(self.h, ptr(a) if a is not None else None, ptr(out)), "bp_cs_allocate")
+        return _vars_out(out)[0]
+
+    def allocate_multiplier(self, assignments=None):
+        out = np.zeros((3, 2), dtype=np.uint32)
+        if assignments is None:
+            check(lib().bp_cs_allocate_multiplier(self.h, None, None, ptr(out)), "bp_cs_allocate_multiplier")
+        else:
+            l, r = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4) for x in assignments]
+            check(lib().bp_cs_allocate_multiplier(self.h, ptr(l), ptr(r), ptr(out)), "bp_cs_allocate_multiplier")
+        return _vars_out(out)
+
+    def constrain(self, lc):
+        v, c, n = _lc_arrays(lc)
+        check(lib().bp_cs_constrain(self.h, ptr(v), ptr(c), C.c_size_t(n)), "bp_cs_constrain")
+
+    def allocate_multipliers(self, left=None, right=None, count=None):
+        """bulk allocate_multiplier: returns the index of the first new multiplier"""
+        first = C.c_uint32(0)
+        if left is None:
+            check(lib().bp_cs_allocate_multipliers(self.h, None, None, C.c_size_t(count), C.byref(first)), "bp_cs_allocate_multipliers")
+        else:
+            l, r = u64arr(left, 4), u64arr(right, 4)
+            check(lib().bp_cs_allocate_multipliers(self.h, ptr(l), ptr(r), C.c_size_t(len(l)), C.byref(first)), "bp_cs_allocate_multipliers")
+        return first.value
+
+    def constrain_many(self, vars_, coefs, offsets):
+        """bulk constrain in CSR form: constraint q owns terms [offsets[q], offsets[q+1])"""
+        v = np.ascontiguousarray(vars_, dtype=np.uint32).reshape(-1, 2)
+        c = u64arr(coefs, 4)
+        off = (C.c_size_t * len(offsets))(*[int(x) for x in offsets])
+        check(lib().bp_cs_constrain_many(self.h, ptr(v), ptr(c), off, C.c_size_t(len(offsets) - 1)), "bp_cs_constrain_many")
+
+    def specify_randomized_constraints(self, fn):
+        """fn(cs) runs in the randomized phase of prove / verify; cs.challenge_scalar(label) is available inside it"""
+        me = self
+
+        def thunk(_user, handle):
+            try:
+                view = me if handle == me.h.value else _ConstraintSystem(me.curve, None, C.c_void_p(handle))
+                try:
+                    fn(view)
+                finally:
+                    if view is not me:
+                        view.h = None   # a borrowed handle (a like-instance of this gadget): not ours to free
+                return 0
+            except Exception as e:  # never unwind through C
+                me._cb_errors.append(e)
+                return -100
+
+        cb = _RANDOMIZE_CB(thunk)
+        self._cbs.append(cb)
+        check(lib().bp_cs_specify_randomized_constraints(self.h, cb, None), "bp_cs_specify_randomized_constraints")
+
+    def challenge_scalar(self, label):
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib().bp_cs_challenge_scalar(self.h, bytes(label) + b"\0", ptr(out)), "bp_cs_challenge_scalar")
+        return out
+
+    def metrics(self):
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        check(lib().bp_cs_metrics(self.h, C.byref(a), C.byref(b), C.byref(c)), "bp_cs_metrics")
+        return a.value, b.value, c.value
+
+
+class ProverCS(_ConstraintSystem):
+    """r1cs::Prover (src/r1cs/prover.rs): `ProverCS(curve, transcript)` = Prover::new(&pc_gens, transcript)"""
+
+    def __init__(self, curve, transcript):
+        super().__init__(curve, transcript)
+        check(lib().bp_prover_new(curve, transcript.h, C.byref(self.h)), "bp_prover_new")
+
+    def commit(self, v, v_blinding, engine=None):
+        """Prover::commit for one value or for arrays of values: returns (V points (count, 8), variables)"""
+        v, b = u64arr(v, 4), u64arr(v_blinding, 4)
+        V = np.zeros((len(v), 8), dtype=np.uint64)
+        vars_ = np.zeros((len(v), 2), dtype=np.uint32)
+        check(lib().bp_prover_commit(self.h, engine.ctx if engine is not None else None, ptr(v), ptr(b), C.c_size_t(len(v)), ptr(V), ptr(vars_)), "bp_prover_commit")
+        return V, _vars_out(vars_)
+
+    def prove(self, engine, rng_bytes):
+        """Prover::prove(prng, &bp_gens): rng_bytes = the 32 bytes the external prng yields; returns R1CSProof::to_bytes()"""
+        buf = C.create_string_buffer(1 << 16)
+        plen = C.c_size_t(len(buf))
+        rc = lib().bp_prover_prove(engine.ctx, self.h, bytes(rng_bytes), buf, C.byref(plen), None)
+        if self._cb_errors:
+            raise self._cb_errors[0]
+        check(rc, "bp_prover_prove")
+        return buf.raw[: plen.value]
+
+
+class VerifierCS(_ConstraintSystem):
+    """r1cs::Verifier (src/r1cs/verifier.rs): `VerifierCS(curve, transcript)` = Verifier::new(transcript);
+    `VerifierCS(curve, transcript, like=v0)` = the next instance of v0's gadget without recording it again."""
+
+    def __init__(self, curve, transcript, like=None):
+        super().__init__(curve, transcript)
+        if like is None:
+            check(lib().bp_verifier_new(curve, transcript.h, C.byref(self.h)), "bp_verifier_new")
+        else:
+            check(lib().bp_verifier_new_like(like.h, transcript.h, C.byref(self.h)), "bp_verifier_new_like")
+            self._like = like   # its callbacks (ctypes thunks) serve this instance too
+
+    def commit(self, V):
+        V = u64arr(V, 8)
+        vars_ = np.zeros((len(V), 2), dtype=np.uint32)
+        check(lib().bp_verifier_commit(self.h, ptr(V), C.c_size_t(len(V)), ptr(vars_)), "bp_verifier_commit")
+        return _vars_out(vars_)
+
+    def verify(self, engine, proof):
+        """Verifier::verify(&proof, &pc_gens, &bp_gens): returns the C status (0 = Ok(()))"""
+        return lib().bp_verifier_verify(engine.ctx, self.h, bytes(proof), C.c_size_t(len(proof)))
+
+
+def batch_verify_cs(engine, verifiers, proofs, alphas=None, want_point=False):
+    """batch_verify(prng, instances, ..) over VerifierCS objects; alphas: (count, 4) words drawn by the caller (None = ones).
+    Returns the status, or (status, mega-check point) with want_point."""
+    n = len(verifiers)
+    hs = (C.c_void_p * max(n, 1))(*[v.h for v in verifiers])
+    blob = b"".join(bytes(p) for p in proofs)
+    lens = (C.c_size_t * max(n, 1))(*[len(p) for p in proofs])
+    al = None if alphas is None else u64arr(alphas, 4)
+    pt = np.zeros(8, dtype=np.uint64)
+    rc = lib().bp_r1cs_batch_verify(engine.ctx, C.c_size_t(n), hs, blob, lens, ptr(al) if al is not None else None, None, ptr(pt))
+    for v in verifiers:
+        if v._cb_errors:
+            raise v._cb_errors[0]
+        src = getattr(v, "_like", None)
+        if src is not None and src._cb_errors:
+            raise src._cb_errors[0]
+    return (rc, pt) if want_point else rc
+
+
+def transcript_state(t):
+    out = C.create_string_buffer(203)
+    check(lib().bp_transcript_export_state(t.h, out), "bp_transcript_export_state")
+    return out.raw
+
+
+def transcript_from_state(state):
+    t = HostTranscript(b"")
+    check(lib().bp_transcript_import_state(t.h, bytes(state)), "bp_transcript_import_state")
+    return t

@@ -180,6 +180,10 @@ int bp_pedersen_commit_batch(bp_ctx* ctx, const uint64_t* v, const uint64_t* bli
  * proof uses its own bp_ctx (stream + workspaces); bp_gens_share lets them all read one resident copy of the tables.
  * bp_stmt_prove consumes the statement (`prove(self, ..)`); timing as in bp_r1cs_prove_scenario ([1] = 0). */
 typedef struct bp_stmt bp_stmt;
+struct bp_cs;
+/* a statement IS a prover handle (scenario code records through the same recorder as bp_cs_*): bp_stmt_prove / _precompute are
+ * bp_prover_prove / _precompute on it */
+struct bp_cs* bp_stmt_as_prover(bp_stmt* stmt);
 int bp_stmt_prover_create(int curve, int scenario, const uint64_t* params, const uint8_t seed[32], bp_stmt** out);
 /* same, with the statement's Pedersen commitments (`Prover::commit`, src/r1cs/prover.rs:327-341) computed on ctx's GPU in one
  * batch; the curve is ctx's.  Identical statement (same transcript, same commitments) as the host-only constructor. */
@@ -195,6 +199,99 @@ int bp_stmt_precompute(bp_stmt* stmt);
 int bp_stmt_precompute_batch(bp_stmt** stmts, size_t count);
 int bp_stmt_prove(bp_ctx* ctx, bp_stmt* stmt, uint8_t* proof_out, size_t* proof_len, double* timing);
 int bp_gens_share(bp_ctx* dst, bp_ctx* src);
+
+/* ---- r1cs::ConstraintSystem / Prover / Verifier for the caller's OWN gadgets ------------------------------------------------
+ * The reference's public surface for circuits is the trait API of src/r1cs/constraint_system.rs:19-135 (`multiply`, `allocate`,
+ * `allocate_multiplier`, `constrain`, `specify_randomized_constraints`, `challenge_scalar`), recorded by `Prover` (src/r1cs/
+ * prover.rs:96-268) and `Verifier` (src/r1cs/verifier.rs:69-224) and consumed by `prove` (prover.rs:444-831), `verify`
+ * (verifier.rs:549-600) and `batch_verify` (verifier.rs:604-691).  A bp_cs is one such recorder; everything it records reaches the
+ * same GPU path the scenario entry points use (they are callers of this API): the fused prover with GPU flattened constraints, the
+ * TranscriptRng x8 pipeline, circuit templates and the block pipeline of batch verification — for single-phase and randomized
+ * (two-phase) circuits alike.
+ *
+ *   Variable            bp_var {kind, index}: r1cs::Variable::{Committed(i), MultiplierLeft(i), MultiplierRight(i),
+ *                       MultiplierOutput(i), One()} (src/r1cs/linear_combination.rs:12-24)
+ *   LinearCombination   n terms as two parallel arrays: vars[n], coefs[4n] (ark Montgomery words)
+ *   transcript          a bp_transcript_* handle, BORROWED for the life of the bp_cs like `T: BorrowMut<Transcript>`: the recorder
+ *                       appends to it exactly what the reference appends, so afterwards it is in the state
+ *                       `prove_and_return_transcript` / `verify_and_return_transcript` would return.  Hosts with their own merlin
+ *                       move the 203-byte STROBE state across with bp_transcript_export_state / bp_transcript_import_state.
+ *   external rng        `prove(prng, ..)` uses its rng for ONE thing: the 32 bytes of TranscriptRngBuilder::finalize (prover.rs:493);
+ *                       the caller draws them (`prng.fill_bytes(&mut [0u8; 32])`) and passes them as rng_bytes.
+ *   alphas              batch_verify's `G::ScalarField::rand(prng)` per instance (verifier.rs:649): drawn by the caller, in
+ *                       instance order (ark Montgomery words); NULL = all ones (what Verifier::verify amounts to).
+ * A bp_cs is not thread-safe; distinct handles are independent.  Errors are the reference's: BP_E_MISSING <-> MissingAssignment,
+ * BP_E_VERIFICATION, BP_E_FORMAT, BP_E_GENS_LENGTH; a non-zero return of a randomized-constraint callback is passed through
+ * (`R1CSError::GadgetError`). */
+typedef struct bp_cs bp_cs;
+#define BP_VAR_COMMITTED 0
+#define BP_VAR_MULT_LEFT 1
+#define BP_VAR_MULT_RIGHT 2
+#define BP_VAR_MULT_OUT 3
+#define BP_VAR_ONE 4
+typedef struct bp_var { uint32_t kind; uint32_t index; } bp_var;
+
+/* `Prover::new(&pc_gens, transcript)` (prover.rs:291-308) / `Verifier::new(transcript)` (verifier.rs:252-263): appends the r1cs
+ * domain separator.  pc_gens is PedersenGens::default() (bp_pedersen_gens). */
+int bp_prover_new(int curve, void* transcript, bp_cs** out);
+int bp_verifier_new(int curve, void* transcript, bp_cs** out);
+void bp_cs_free(bp_cs* cs);
+/* `ConstraintSystem::transcript()` (constraint_system.rs:21): the recorder's transcript, for gadgets that bind extra data */
+void* bp_cs_transcript(bp_cs* cs);
+/* `Prover::commit(v, v_blinding) -> (V, Variable)` (prover.rs:327-341) for `count` values in order; with a ctx the Pedersen
+ * commitments are one GPU batch (bp_pedersen_commit_batch), otherwise host arithmetic.  V_xy_out / vars_out may be NULL. */
+int bp_prover_commit(bp_cs* prover, bp_ctx* ctx_or_null, const uint64_t* v, const uint64_t* v_blinding, size_t count, uint64_t* V_xy_out, bp_var* vars_out);
+/* `Verifier::commit(V) -> Variable` (verifier.rs:279-287) for `count` commitments in order */
+int bp_verifier_commit(bp_cs* verifier, const uint64_t* V_xy, size_t count, bp_var* vars_out);
+/* `multiply(left, right) -> (l, r, o)` (constraint_system.rs:30-41; prover.rs:103-133, verifier.rs:74-98) */
+int bp_cs_multiply(bp_cs* cs, const bp_var* left_vars, const uint64_t* left_coefs, size_t n_left, const bp_var* right_vars, const uint64_t* right_coefs,
+                   size_t n_right, bp_var out[3]);
+/* `allocate(assignment)` (constraint_system.rs:43-54; prover.rs:135-157, verifier.rs:100-116); NULL = None (BP_E_MISSING for a prover) */
+int bp_cs_allocate(bp_cs* cs, const uint64_t* assignment_or_null, bp_var* out);
+/* `allocate_multiplier(input_assignments)` (constraint_system.rs:56-65; prover.rs:159-183, verifier.rs:118-138) */
+int bp_cs_allocate_multiplier(bp_cs* cs, const uint64_t* left_or_null, const uint64_t* right_or_null, bp_var out[3]);
+/* `constrain(lc)` (constraint_system.rs:70-75) */
+int bp_cs_constrain(bp_cs* cs, const bp_var* vars, const uint64_t* coefs, size_t n);
+/* bulk forms for large gadgets (one FFI call instead of one per gate): `count` allocate_multiplier calls (left / right: count x 4
+ * words, NULL for a verifier; the multipliers get indices first_index .. first_index + count - 1), and `nconstraints` constrain
+ * calls in CSR form (constraint q owns terms [offsets[q], offsets[q+1]) of vars / coefs) */
+int bp_cs_allocate_multipliers(bp_cs* cs, const uint64_t* left, const uint64_t* right, size_t count, uint32_t* first_index);
+int bp_cs_constrain_many(bp_cs* cs, const bp_var* vars, const uint64_t* coefs, const size_t* offsets, size_t nconstraints);
+/* `specify_randomized_constraints(callback)` (constraint_system.rs:96-109; prover.rs:211-217, verifier.rs:172-178): cb runs in the
+ * randomized phase of prove / verify (prover.rs:418-441, verifier.rs:353-376) with the recorder it belongs to; inside it
+ * bp_cs_challenge_scalar is `RandomizedConstraintSystem::challenge_scalar(label)` (constraint_system.rs:127-134).  In batch
+ * verification the callbacks of different instances run concurrently on the library's host threads. */
+typedef int (*bp_randomize_cb)(void* user, bp_cs* cs);
+int bp_cs_specify_randomized_constraints(bp_cs* cs, bp_randomize_cb cb, void* user);
+int bp_cs_challenge_scalar(bp_cs* cs, const char* label, uint64_t out[4]);
+int bp_cs_metrics(bp_cs* cs, size_t* multipliers, size_t* constraints, size_t* commitments);
+/* `prover.prove(prng, &bp_gens)` (prover.rs:444-451): consumes the prover.  rng_bytes: see "external rng" above (may be NULL when
+ * bp_prover_set_rng / bp_prover_precompute supplied them).  proof_out / *proof_len: `R1CSProof::to_bytes` (proof.rs:74-81).
+ * timing (8 doubles, may be NULL) as in bp_r1cs_prove_scenario.  bp_gens are the ctx's resident tables.
+ * bp_prover_precompute[_batch]: the host-only head of prove() (TranscriptRng chain), see bp_stmt_precompute. */
+int bp_prover_set_rng(bp_cs* prover, const uint8_t rng_bytes[32]);
+int bp_prover_precompute(bp_cs* prover, const uint8_t rng_bytes_or_null[32]);
+int bp_prover_precompute_batch(bp_cs** provers, size_t count);
+int bp_prover_prove(bp_ctx* ctx, bp_cs* prover, const uint8_t rng_bytes_or_null[32], uint8_t* proof_out, size_t* proof_len, double* timing);
+/* `verifier.verify(&proof, &pc_gens, &bp_gens)` (verifier.rs:549-557): consumes the verifier */
+int bp_verifier_verify(bp_ctx* ctx, bp_cs* verifier, const uint8_t* proof, size_t proof_len);
+/* `batch_verify(prng, instances, &pc_gens, &bp_gens)` (verifier.rs:604-691): instance k = (verifiers[k], the k-th of the
+ * concatenated compressed proofs); every verifier is consumed.  Instances whose recordings have the same STRUCTURE (same gadget;
+ * coefficient values may differ: public constants, challenge-dependent randomized constraints) are evaluated by one kernel launch
+ * per block of 512 from a GPU-resident circuit template.  check_point_xy (may be NULL): the value of the mega-check MSM, all-zero
+ * iff it is the identity.  timing (5 doubles, may be NULL) as in bp_r1cs_batch_verify_scenarios. */
+int bp_r1cs_batch_verify(bp_ctx* ctx, size_t count, bp_cs* const* verifiers, const uint8_t* proofs, const size_t* proof_lens, const uint64_t* alphas,
+                         double* timing, uint64_t* check_point_xy);
+/* The next instance of the SAME gadget without recording it again: a verifier that shares `of`'s phase-1 constraints and its
+ * randomized-constraint callbacks (ref-counted, immutable from now on: `of` and the new verifier accept commits and randomized
+ * constraints only).  The caller replays just the instance's own transcript traffic: bp_verifier_commit in the same order as on
+ * `of`, plus whatever the gadget appends through bp_cs_transcript.  The reference has no such call — every `Verifier` there records
+ * its gadget anew (verifier.rs:69-224); with 4096 instances of a 2^14-multiplier circuit that recording is the whole cost. */
+int bp_verifier_new_like(bp_cs* of, void* transcript, bp_cs** out);
+/* merlin::Transcript <-> bp_transcript handle: Strobe128 {state[200], pos, pos_begin, cur_flags} (merlin 3.0 src/strobe.rs) */
+int bp_transcript_export_state(const void* transcript, uint8_t out[203]);
+int bp_transcript_import_state(void* transcript, const uint8_t in[203]);
+void* bp_transcript_clone(const void* transcript);
 
 /* ---- r1cs::Verifier::verify / batch_verify ------------------------------------------------------------
  * bp_r1cs_verify_scenario replaces `Verifier::new` + commits + gadget + `verify(&proof, &pc_gens, &bp_gens)`

@@ -316,4 +316,138 @@ int orc_batch_verify(int curve, size_t count, const int* scenarios, const u64* p
     return e;
 }
 
+// same, also returning the value of the mega-check MSM (identity = all-zero) so a failing batch can be compared point for point
+int orc_batch_verify_point(int curve, size_t count, const int* scenarios, const u64* params, size_t gens_cap, const u8* proofs, const size_t* proof_lens,
+                           const u64* commit_xy, const size_t* ms, const u64* publics, const size_t* npubs, const u8* alpha_seed, u64* point_out) {
+    const BulletproofGens& bp = gens_for(curve, gens_cap);
+    const Curve& C = g_curves[curve];
+    std::vector<std::unique_ptr<Transcript>> trs;
+    std::vector<std::unique_ptr<Verifier>> vs;
+    std::vector<R1CSProof> pfs(count);
+    std::vector<std::pair<Verifier*, const R1CSProof*>> inst;
+    size_t poff = 0, coff = 0, uoff = 0;
+    for (size_t k = 0; k < count; k++) {
+        Err e = R1CSProof::from_bytes(C, proofs + poff, proof_lens[k], pfs[k]);
+        if (e) return e;
+        trs.emplace_back(new Transcript(scenario_label(scenarios[k])));
+        vs.emplace_back(new Verifier(C, *trs.back()));
+        e = build_verifier(*vs.back(), scenarios[k], params + 8 * k, commit_xy + 8 * coff, ms[k], publics + 4 * uoff, npubs[k]);
+        if (e) return e;
+        poff += proof_lens[k]; coff += ms[k]; uoff += npubs[k];
+    }
+    for (size_t k = 0; k < count; k++) inst.push_back({vs[k].get(), &pfs[k]});
+    ChaCha20Rng prng; prng.seed(alpha_seed);
+    Aff mega; mega.inf = true;
+    Err e = batch_verify(C, prng, inst, g_pc[curve], bp, nullptr, &mega);
+    if (point_out) aff_out(point_out, mega);
+    return e;
+}
+
+// ---- the reference's ConstraintSystem trait as handles (src/r1cs/constraint_system.rs:19-135), so that a test can run ANY
+// gadget — not only the scenarios above — on the restated Prover / Verifier and compare with the product's own recorder.
+// Variables cross the boundary as (kind, index) pairs of u32; linear combinations as parallel arrays (vars, coefficients).
+struct OrcCs {
+    int curve; bool proving;
+    Transcript tr;
+    std::unique_ptr<Prover> p;
+    std::unique_ptr<Verifier> v;
+    CS* cs() { return proving ? (CS*)p.get() : (CS*)v.get(); }
+    OrcCs(int c, bool pr, const u8* label, size_t n) : curve(c), proving(pr), tr(label, n) {}
+};
+struct FixedBytesRng {   // the external prng of Prover::prove is only ever asked for 32 bytes (TranscriptRngBuilder::finalize)
+    const u8* b;
+    void fill_bytes(u8* dst, size_t n) { memcpy(dst, b, n); }
+};
+typedef int (*orc_randomize_cb)(void* user, void* cs_handle);
+static LC lc_in(const u32* vars, const u64* coefs, size_t n) {
+    LC l;
+    for (size_t i = 0; i < n; i++) { Variable v; v.k = (VarKind)vars[2 * i]; v.i = vars[2 * i + 1]; l.terms.push_back({v, *(const Fe*)(coefs + 4 * i)}); }
+    return l;
+}
+static void var_out(u32* o, const Variable& v) { o[0] = (u32)v.k; o[1] = (u32)v.i; }
+
+// Prover::new / Verifier::new on a transcript created with `label` (the caller may append to it first through orc_cs_transcript)
+void* orc_cs_new(int curve, int proving, void* transcript_or_null, const u8* label, size_t n) {
+    init_once();
+    OrcCs* h = new OrcCs(curve, proving != 0, label, n);
+    if (transcript_or_null) h->tr = *(Transcript*)transcript_or_null;
+    if (proving) h->p.reset(new Prover(g_curves[curve], g_pc[curve], h->tr)); else h->v.reset(new Verifier(g_curves[curve], h->tr));
+    return h;
+}
+void orc_cs_free(void* h) { delete (OrcCs*)h; }
+void* orc_cs_transcript(void* h) { return &((OrcCs*)h)->tr; }
+int orc_prover_commit(void* hh, const u64* val, const u64* blind, u64* V_xy, u32* var) {
+    OrcCs* h = (OrcCs*)hh; if (!h->proving) return -1;
+    Variable v; Aff V = h->p->commit(*(const Fe*)val, *(const Fe*)blind, v);
+    aff_out(V_xy, V); var_out(var, v); return 0;
+}
+int orc_verifier_commit(void* hh, const u64* V_xy, u32* var) {
+    OrcCs* h = (OrcCs*)hh; if (h->proving) return -1;
+    var_out(var, h->v->commit(aff_in(V_xy))); return 0;
+}
+int orc_cs_multiply(void* hh, const u32* lv, const u64* lc, size_t nl, const u32* rv, const u64* rc, size_t nr, u32* out3) {
+    Variable o[3]; ((OrcCs*)hh)->cs()->multiply(lc_in(lv, lc, nl), lc_in(rv, rc, nr), o);
+    for (int i = 0; i < 3; i++) var_out(out3 + 2 * i, o[i]);
+    return 0;
+}
+int orc_cs_allocate(void* hh, const u64* assignment, u32* out) {
+    Variable o; Err e = ((OrcCs*)hh)->cs()->allocate((const Fe*)assignment, o);
+    if (e) return e;
+    var_out(out, o); return 0;
+}
+int orc_cs_allocate_multiplier(void* hh, const u64* l, const u64* r, u32* out3) {
+    Variable o[3]; Err e = ((OrcCs*)hh)->cs()->allocate_multiplier((const Fe*)l, (const Fe*)r, o);
+    if (e) return e;
+    for (int i = 0; i < 3; i++) var_out(out3 + 2 * i, o[i]);
+    return 0;
+}
+int orc_cs_constrain(void* hh, const u32* vars, const u64* coefs, size_t n) { ((OrcCs*)hh)->cs()->constrain(lc_in(vars, coefs, n)); return 0; }
+int orc_cs_specify_randomized_constraints(void* hh, orc_randomize_cb cb, void* user) {
+    OrcCs* h = (OrcCs*)hh;
+    return h->cs()->specify_randomized_constraints([cb, user, h](CS&) -> Err { return (Err)cb(user, h); });
+}
+int orc_cs_challenge_scalar(void* hh, const char* label, u64* out) { *(Fe*)out = ((OrcCs*)hh)->cs()->challenge_scalar(label); return 0; }
+// Prover::prove(prng, bp_gens) with the 32 bytes the external prng yields
+int orc_prover_prove(void* hh, const u8* rng_bytes32, size_t gens_cap, u8* proof_out, size_t* proof_len) {
+    OrcCs* h = (OrcCs*)hh; if (!h->proving) return -1;
+    const BulletproofGens& bp = gens_for(h->curve, gens_cap);
+    FixedBytesRng prng{rng_bytes32};
+    R1CSProof proof;
+    Err e = h->p->prove(prng, bp, proof);
+    if (e) return e;
+    std::vector<u8> bytes = proof.to_bytes(g_curves[h->curve]);
+    if (bytes.size() > *proof_len) return -2;
+    memcpy(proof_out, bytes.data(), bytes.size()); *proof_len = bytes.size();
+    return 0;
+}
+int orc_verifier_verify(void* hh, size_t gens_cap, const u8* proof_bytes, size_t proof_len) {
+    OrcCs* h = (OrcCs*)hh; if (h->proving) return -1;
+    const BulletproofGens& bp = gens_for(h->curve, gens_cap);
+    R1CSProof proof;
+    Err e = R1CSProof::from_bytes(g_curves[h->curve], proof_bytes, proof_len, proof);
+    if (e) return e;
+    return h->v->verify(proof, g_pc[h->curve], bp);
+}
+// batch_verify over verifier handles with the caller's alphas (count x 4 words); point_out = the mega-check value
+int orc_cs_batch_verify(int curve, size_t count, void** handles, size_t gens_cap, const u8* proofs, const size_t* proof_lens, const u64* alphas, u64* point_out) {
+    const BulletproofGens& bp = gens_for(curve, gens_cap);
+    const Curve& C = g_curves[curve];
+    std::vector<R1CSProof> pfs(count);
+    std::vector<std::pair<Verifier*, const R1CSProof*>> inst;
+    size_t poff = 0;
+    for (size_t k = 0; k < count; k++) {
+        Err e = R1CSProof::from_bytes(C, proofs + poff, proof_lens[k], pfs[k]);
+        if (e) return e;
+        poff += proof_lens[k];
+        OrcCs* h = (OrcCs*)handles[k];
+        if (h->proving || h->curve != curve) return -1;
+        inst.push_back({h->v.get(), &pfs[k]});
+    }
+    ChaCha20Rng unused; u8 z[32] = {0}; unused.seed(z);
+    Aff mega; mega.inf = true;
+    Err e = batch_verify(C, unused, inst, g_pc[curve], bp, (const Fe*)alphas, &mega);
+    if (point_out) aff_out(point_out, mega);
+    return e;
+}
+
 }  // extern "C"

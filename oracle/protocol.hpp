@@ -732,9 +732,11 @@ struct Verifier : CS {
 };
 
 // src/r1cs/verifier.rs:604-691
+// alphas_in: the per-instance weights the caller drew (instances.size() of them) instead of `Fr::rand(prng)`;
+// mega_out: the value of the final MSM (the check accepts iff it is the identity) — both optional, for parity tests.
 template <class Rng>
 static inline Err batch_verify(const Curve& C, Rng& prng, std::vector<std::pair<Verifier*, const R1CSProof*>>& instances, const PedersenGens& pc,
-                               const BulletproofGens& bp) {
+                               const BulletproofGens& bp, const Fe* alphas_in = nullptr, Aff* mega_out = nullptr) {
     const Field& F = C.fr;
     size_t max_n = 0;
     std::vector<std::vector<Fe>> vs(instances.size());
@@ -750,7 +752,7 @@ static inline Err batch_verify(const Curve& C, Rng& prng, std::vector<std::pair<
     all_elems.insert(all_elems.end(), bp.G_vec[0].begin(), bp.G_vec[0].begin() + max_n);
     all_elems.insert(all_elems.end(), bp.H_vec[0].begin(), bp.H_vec[0].begin() + max_n);
     for (size_t k = 0; k < instances.size(); k++) {
-        Fe alpha = fe_rand(F, prng);
+        Fe alpha = alphas_in ? alphas_in[k] : fe_rand(F, prng);
         std::vector<Fe>& sc = vs[k];
         for (auto& s : sc) F.mul(s, alpha, s);
         size_t padded_n = next_pow2(instances[k].first->num_vars);
@@ -762,6 +764,7 @@ static inline Err batch_verify(const Curve& C, Rng& prng, std::vector<std::pair<
         instances[k].first->tail_points(*instances[k].second, all_elems);
     }
     Jac m = C.msm(all_elems.data(), all_scalars.data(), all_elems.size());
+    if (mega_out) *mega_out = C.to_affine(m);
     return C.is_inf(m) ? OK : E_VERIFICATION;
 }
 

@@ -17,6 +17,7 @@ _LIB = None
 
 SECQ, ZORRO = 0, 1
 SC_SHUFFLE, SC_RANGE, SC_EXAMPLE, SC_SQUARE_CHAIN, SC_MULTI_RANGE = 0, 1, 2, 3, 4
+OK, E_VERIFICATION, E_GENS_LENGTH, E_MISSING_ASSIGNMENT, E_FORMAT, E_GADGET = 0, 1, 2, 3, 4, 5   # protocol.hpp `enum Err`
 
 
 def build():
@@ -117,7 +118,8 @@ class Transcript:
 
     def __del__(self):
         try:
-            lib().orc_transcript_free(self.h)
+            if not getattr(self, "_borrowed", False):
+                lib().orc_transcript_free(self.h)
         except Exception:
             pass
 
@@ -323,3 +325,168 @@ def batch_verify(curve, instances, gens_cap, alpha_seed, timing=None):
     if timing is not None:
         timing.append(t[0])
     return rc
+
+
+# ---- the reference's ConstraintSystem trait on the restated Prover / Verifier (capi.cpp orc_cs_*) ---------------------------
+# Same shapes as ark_bulletproofs_amd.engine.ProverCS / VerifierCS, so one gadget function drives both sides of a parity test.
+VAR_COMMITTED, VAR_MULT_LEFT, VAR_MULT_RIGHT, VAR_MULT_OUT, VAR_ONE = 0, 1, 2, 3, 4
+ONE_VAR = (VAR_ONE, 0)
+_RANDOMIZE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+def _lc_arrays(lc):
+    n = len(lc)
+    vars_ = np.zeros((max(n, 1), 2), dtype=np.uint32)
+    coefs = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    for i, (v, c) in enumerate(lc):
+        vars_[i] = v
+        coefs[i] = np.asarray(c, dtype=np.uint64).reshape(4)
+    return vars_, coefs, n
+
+
+def _vars_out(arr):
+    return [(int(arr[i, 0]), int(arr[i, 1])) for i in range(len(arr))]
+
+
+class _OracleCS:
+    def __init__(self, curve, label, proving):
+        lib().orc_cs_new.restype = C.c_void_p
+        lib().orc_cs_transcript.restype = C.c_void_p
+        self.curve = curve
+        self._pre = Transcript(label)            # the caller's transcript before Prover::new / Verifier::new
+        self.h = None
+        self.proving = proving
+        self._cbs, self._cb_errors = [], []
+
+    def transcript(self):
+        """before start(): the transcript the recorder will be created on; after: the recorder's own"""
+        if self.h is None:
+            return self._pre
+        t = Transcript.__new__(Transcript)
+        t.h = C.c_void_p(lib().orc_cs_transcript(self.h))
+        t._borrowed = True
+        return t
+
+    def start(self):
+        self.h = C.c_void_p(lib().orc_cs_new(self.curve, int(self.proving), self._pre.h, b"", C.c_size_t(0)))
+        return self
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_cs_free(self.h)
+        except Exception:
+            pass
+
+    def multiply(self, left, right):
+        lv, lc, nl = _lc_arrays(left)
+        rv, rc, nr = _lc_arrays(right)
+        out = np.zeros((3, 2), dtype=np.uint32)
+        assert lib().orc_cs_multiply(self.h, _p(lv), _p(lc), C.c_size_t(nl), _p(rv), _p(rc), C.c_size_t(nr), _p(out)) == 0
+        return _vars_out(out)
+
+    def allocate(self, assignment=None):
+        out = np.zeros((1, 2), dtype=np.uint32)
+        a = None if assignment is None else np.ascontiguousarray(assignment, dtype=np.uint64).reshape(4)
+        rc = lib().orc_cs_allocate(self.h, _p(a) if a is not None else None, _p(out))
+        if rc:
+            raise OracleError(rc)
+        return _vars_out(out)[0]
+
+    def allocate_multiplier(self, assignments=None):
+        out = np.zeros((3, 2), dtype=np.uint32)
+        if assignments is None:
+            rc = lib().orc_cs_allocate_multiplier(self.h, None, None, _p(out))
+        else:
+            l, r = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4) for x in assignments]
+            rc = lib().orc_cs_allocate_multiplier(self.h, _p(l), _p(r), _p(out))
+        if rc:
+            raise OracleError(rc)
+        return _vars_out(out)
+
+    def constrain(self, lc):
+        v, c, n = _lc_arrays(lc)
+        assert lib().orc_cs_constrain(self.h, _p(v), _p(c), C.c_size_t(n)) == 0
+
+    def specify_randomized_constraints(self, fn):
+        me = self
+
+        def thunk(_user, _handle):
+            try:
+                fn(me)
+                return 0
+            except Exception as e:
+                me._cb_errors.append(e)
+                return -100
+
+        cb = _RANDOMIZE_CB(thunk)
+        self._cbs.append(cb)
+        assert lib().orc_cs_specify_randomized_constraints(self.h, cb, None) == 0
+
+    def challenge_scalar(self, label):
+        out = _u64(4)
+        lib().orc_cs_challenge_scalar(self.h, bytes(label) + b"\0", _p(out))
+        return out
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        self.code = code
+        super().__init__("oracle error %d" % code)
+
+
+class ProverCS(_OracleCS):
+    def __init__(self, curve, label):
+        super().__init__(curve, label, True)
+
+    def commit(self, v, v_blinding):
+        v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(v_blinding, dtype=np.uint64).reshape(-1, 4)
+        V = np.zeros((len(v), 8), dtype=np.uint64)
+        vars_ = np.zeros((len(v), 2), dtype=np.uint32)
+        for i in range(len(v)):
+            assert lib().orc_prover_commit(self.h, _p(v[i]), _p(b[i]), _p(V[i]), _p(vars_[i])) == 0
+        return V, _vars_out(vars_)
+
+    def prove(self, gens_cap, rng_bytes):
+        buf = C.create_string_buffer(1 << 16)
+        plen = C.c_size_t(len(buf))
+        rc = lib().orc_prover_prove(self.h, bytes(rng_bytes), C.c_size_t(gens_cap), buf, C.byref(plen))
+        if self._cb_errors:
+            raise self._cb_errors[0]
+        if rc:
+            raise OracleError(rc)
+        return buf.raw[: plen.value]
+
+
+class VerifierCS(_OracleCS):
+    def __init__(self, curve, label):
+        super().__init__(curve, label, False)
+
+    def commit(self, V):
+        V = np.ascontiguousarray(V, dtype=np.uint64).reshape(-1, 8)
+        vars_ = np.zeros((len(V), 2), dtype=np.uint32)
+        for i in range(len(V)):
+            assert lib().orc_verifier_commit(self.h, _p(V[i]), _p(vars_[i])) == 0
+        return _vars_out(vars_)
+
+    def verify(self, gens_cap, proof):
+        rc = lib().orc_verifier_verify(self.h, C.c_size_t(gens_cap), bytes(proof), C.c_size_t(len(proof)))
+        if self._cb_errors:
+            raise self._cb_errors[0]
+        return rc
+
+
+def batch_verify_cs(curve, verifiers, proofs, gens_cap, alphas):
+    """returns (status, mega-check point)"""
+    n = len(verifiers)
+    hs = (C.c_void_p * max(n, 1))(*[v.h for v in verifiers])
+    blob = b"".join(bytes(p) for p in proofs)
+    lens = (C.c_size_t * max(n, 1))(*[len(p) for p in proofs])
+    al = np.ascontiguousarray(alphas, dtype=np.uint64).reshape(-1, 4)
+    pt = _u64(8)
+    rc = lib().orc_cs_batch_verify(curve, C.c_size_t(n), hs, C.c_size_t(gens_cap), blob, lens, _p(al), _p(pt))
+    for v in verifiers:
+        if v._cb_errors:
+            raise v._cb_errors[0]
+    return rc, pt
