@@ -434,12 +434,23 @@ def run_verify(args, rank, world, local):
 
     nval, nbits = 256, 64
     N = nval * nbits
+    shuffle_k = args.shuffle_k
+    if shuffle_k:
+        # the reference's own verification benchmark circuit (benches/r1cs_secq256k1.rs:201-250): a k-shuffle, all of whose
+        # 2(k-1) multipliers are randomized (phase-2) constraints carrying the instance's challenge; m = 2k commitments
+        N = 1
+        while N < 2 * (shuffle_k - 1):
+            N *= 2
     eng = A.Engine(curve=args.curve, device=local)
-    eng.gens_derive(N)
+    eng.gens_derive(max(N, 2))
     distinct = []
     for i in range(args.distinct):
-        pr = eng.prove_scenario(E.SC_MULTI_RANGE, [nval, nbits, 0], statement_seed(1, i), m_cap=nval + 8)
-        distinct.append((E.SC_MULTI_RANGE, [nval, nbits, 0], pr.proof, pr.commitments, pr.publics))
+        if shuffle_k:
+            pr = eng.prove_scenario(E.SC_SHUFFLE, [shuffle_k], statement_seed(2, i), m_cap=2 * shuffle_k + 8)
+            distinct.append((E.SC_SHUFFLE, [shuffle_k], pr.proof, pr.commitments, pr.publics))
+        else:
+            pr = eng.prove_scenario(E.SC_MULTI_RANGE, [nval, nbits, 0], statement_seed(1, i), m_cap=nval + 8)
+            distinct.append((E.SC_MULTI_RANGE, [nval, nbits, 0], pr.proof, pr.commitments, pr.publics))
     total = args.proofs * world
     lo, hi = P.shard_range(total, rank, world)
     inst_list = [distinct[i % len(distinct)] for i in range(lo, hi)]
@@ -461,15 +472,18 @@ def run_verify(args, rank, world, local):
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     assert ok, "batch verification of valid proofs failed"
-    k = 14
-    per_proof_bytes = 352 * N + 96 * (13 + nval + 2 * k)
+    k = int(np.log2(N))
+    m_commit = 2 * shuffle_k if shuffle_k else nval
+    per_proof_bytes = 352 * N + 96 * (13 + m_commit + 2 * k)
     vs_ms, vs_n = eng.kernel_time(5)
     res = {
         "metric": "r1cs_batch_verifies_per_sec", "value": total * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE, "data": "synthetic",
-        "config": {"workload": "cfg4: batch_verify of %d R1CS proofs per GPU, 2^14 constraints each (256 x 64-bit range proofs, m=256), %s"
-                               % (args.proofs, CURVES[args.curve]),
+        "config": {"workload": ("batch_verify of %d k-shuffle proofs per GPU (k = %d: %d randomized multipliers padded to %d, m = %d; benches/r1cs_secq256k1.rs:201-250), %s"
+                                % (args.proofs, shuffle_k, 2 * (shuffle_k - 1), N, m_commit, CURVES[args.curve])) if shuffle_k else
+                               ("cfg4: batch_verify of %d R1CS proofs per GPU, 2^14 constraints each (256 x 64-bit range proofs, m=256), %s"
+                                % (args.proofs, CURVES[args.curve])),
                    "proofs_per_gpu": args.proofs, "distinct_proofs": len(distinct), "constraints_per_proof": N, "parallelism": "proof-sharded x%d" % world,
                    "stage_ms_per_step": {"whole_call": tms[0] / args.steps * 1e3, "host_replay_overlapped_with_gpu": tms[1] / args.steps * 1e3,
                                          "gpu_drain_and_tail_scaling": tms[2] / args.steps * 1e3, "final_msm": tms[3] / args.steps * 1e3,
@@ -483,7 +497,7 @@ def run_verify(args, rank, world, local):
         nproofs_per_launch = inst.n * args.steps / max(vs_n, 1)  # the batch goes through in blocks of 512 proofs, one k_vfy_batch launch each
         res["roofline"] = {"bound": "hbm", "kernel": "k_vfy_batch (one launch per block of 512 proofs)", "achieved": 160.0 * N * nproofs_per_launch / avg_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * N * nproofs_per_launch / avg_s / 1e9 / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic("verify4096/k_vfy_batch<Secq>", args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512, "r01_pmc_verify_4096_summary.json"),
+                           "traffic": pmc_traffic("verify4096/k_vfy_batch<Secq>", args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512 and not shuffle_k, "r01_pmc_verify_4096_summary.json"),
                            "avg_kernel_ms": vs_ms / vs_n, "algorithmic_bytes_per_verify": per_proof_bytes}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         from oracle import pyoracle as O
@@ -539,6 +553,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
+    ap.add_argument("--shuffle-k", type=int, default=0, help="verify workload: batches of k-shuffle proofs (the reference's two-phase benchmark circuit) instead of cfg4's range proofs")
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
     ap.add_argument("--cpu-verify-proofs", type=int, default=256, help="CPU baseline sample of the verify workload (about 10 s)")
