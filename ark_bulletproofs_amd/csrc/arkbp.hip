@@ -78,6 +78,12 @@ struct IpaState {
     bool allow_freeze = false, frozen = false;
     size_t n0 = 0;
     u32 *d_cG = nullptr, *d_cH = nullptr;
+    // multi-GPU: how the L / R MSMs of this instance treat the ctx's shard mode (see msm_run): -1 = the ctx default (window
+    // partition + point-reduce), 2 = this rank's terms are its own slice of the vectors (index-cyclic IPA): all windows, then the
+    // point-reduce, 0 = replicated (every rank computes the same small MSM: the frozen tail after the gather)
+    int msm_mode = -1;
+    F4 geo_k0;                  // index-cyclic slices: the geometric H factor of local element j is K * rho^(rank + j*world) = (K * geo_k0) * (rho^world)^j
+    bool have_k0 = false;
 };
 
 struct bp_ctx {
@@ -121,6 +127,10 @@ struct bp_ctx {
     int shard_rank = 0, shard_world = 1;
     bp_point_reduce_cb shard_cb = nullptr;
     void* shard_user = nullptr;
+    bp_allgather_cb gather_cb = nullptr;   // optional: lets the prover partition the IPA index-cyclically (bp_ctx_set_shard_allgather)
+    void* gather_user = nullptr;
+    size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
+    DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
     IpaState ipa_step;         // bp_ipa_begin .. bp_ipa_finish
     bool ipa_step_active = false;
     u32* h_totals = nullptr;  // pinned
@@ -172,7 +182,9 @@ static MsmPlan msm_plan(size_t n, int bits) {
 }
 
 template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u32* d_scalars, size_t n, int scalars_mont, J4& result,
-                                      int w_lo = 0, int w_hi = -1 /* window range for multi-GPU window sharding; default all */) {
+                                      int w_lo = 0, int w_hi = -1 /* window range for multi-GPU window sharding; default all */,
+                                      int shard_mode = -1 /* -1: the ctx's mode (window partition + reduce when world > 1); 0: none (replicated);
+                                                             2: the terms are this rank's own share: all windows, then the point-reduce */) {
     typedef host::Grp<C> G;
     typedef host::Fld<typename C::Fq> F;
     result = G::inf();
@@ -180,8 +192,8 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (n >= (1u << 31)) { g_err = "msm: n too large"; return BP_E_ARG; }
     hipStream_t st = ctx->stream;
     MsmPlan pl = msm_plan(n, C::Fr::BITS);
-    const bool sharded = w_hi < 0 && ctx->shard_world > 1;
-    if (sharded) {   // contiguous block partition of the windows (the same rule as parallel.shard_range)
+    const bool sharded = w_hi < 0 && ctx->shard_world > 1 && shard_mode != 0;
+    if (sharded && shard_mode != 2) {   // contiguous block partition of the windows (the same rule as parallel.shard_range)
         const int base = pl.W / ctx->shard_world, rem = pl.W % ctx->shard_world, r = ctx->shard_rank;
         w_lo = r * base + std::min(r, rem);
         w_hi = w_lo + base + (r < rem ? 1 : 0);
@@ -604,8 +616,8 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
         sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n0; sg.start[2] = (u32)(2 * n0); sg.start[3] = (u32)(2 * n0 + 1);
         sg.ptr[0] = s.d_G; sg.ptr[1] = s.d_H; sg.ptr[2] = s.d_Q;
         J4 Lj, Rj;
-        BPCHK(msm_run<C>(ctx, sg, sL, 2 * n0 + 1, 0, Lj));
-        BPCHK(msm_run<C>(ctx, sg, sR, 2 * n0 + 1, 0, Rj));
+        BPCHK(msm_run<C>(ctx, sg, sL, 2 * n0 + 1, 0, Lj, 0, -1, s.msm_mode));
+        BPCHK(msm_run<C>(ctx, sg, sR, 2 * n0 + 1, 0, Rj, 0, -1, s.msm_mode));
         A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
         memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
         memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
@@ -622,9 +634,9 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
     sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n; sg.start[2] = (u32)(2 * n); sg.start[3] = (u32)(2 * n + 1);
     sg.ptr[0] = s.d_G + n * 16; sg.ptr[1] = s.d_H; sg.ptr[2] = s.d_Q;
     J4 Lj, Rj;
-    BPCHK(msm_run<C>(ctx, sg, sL, 2 * n + 1, 0, Lj));
+    BPCHK(msm_run<C>(ctx, sg, sL, 2 * n + 1, 0, Lj, 0, -1, s.msm_mode));
     sg.ptr[0] = s.d_G; sg.ptr[1] = s.d_H + n * 16;
-    BPCHK(msm_run<C>(ctx, sg, sR, 2 * n + 1, 0, Rj));
+    BPCHK(msm_run<C>(ctx, sg, sR, 2 * n + 1, 0, Rj, 0, -1, s.msm_mode));
     A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
     memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
     memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
@@ -665,6 +677,7 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
                                          S::mul(S::mul(S::sqr(u), S::mul(s.gf_halves[0], ginv)), s.rho_pw[k]), 3));
             s.gamma_G = S::mul(s.gamma_G, s2);
             s.gamma_H = S::mul(S::mul(ui, s.gf_halves[1]), s.rho_pw[32 + k]);
+            if (s.have_k0) s.gamma_H = S::mul(s.gamma_H, s.geo_k0);
             s.pending = true; s.h_geo = true;
         } else if (gf_ok) {
             // G: u^-1*gL*G_L + u*gR*G_R = (u*gR) * (G_R + t*G_L), t = u^-1*gL / (u*gR): uniform, one NAF ladder; H: per-lane factors
@@ -744,6 +757,132 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
         BPCHK(ipa_round_fold<C>(ctx, s, uw));
     }
     return ipa_finish_dev<C>(ctx, s, a_out, b_out);
+}
+
+// ---- index-cyclic InnerProductProof::create inside a sharded prover -------------------------------------------
+// Rank r of `world` keeps the elements i = r + j*world of a, b, G, H and of the factor vectors: element i and its fold partner
+// i + n/2 live on the same rank while n >= 2*world, so every fold is local and 1/world of the single-GPU work.  A round's L and R
+// are sums of per-rank partial MSMs (the <a_L, b_R> * Q term is linear too): the ctx's point-reduce callback.  When the global
+// length reaches the frozen-tail length the ranks all-gather what is left (a few hundred elements) and every rank finishes the
+// remaining rounds over the frozen generators, replicated.  L, R, a, b are bit-identical to the single-GPU result.
+template <class W8> __global__ void k_cyclic_gather(const u32* __restrict__ in, u32* __restrict__ out, u32 n_loc, u32 rank, u32 world) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_loc) return;
+    const W8* src = (const W8*)in + ((size_t)rank + (size_t)j * world);
+    ((W8*)out)[j] = *src;
+}
+struct Blk32 { uint4 a, b; };
+struct Blk64 { uint4 a, b, c, d; };
+template <class C>
+static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, const u32* d_Gtab, const u32* d_Htab, const u32* d_a, const u32* d_b,
+                             size_t N, const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4],
+                             const F4* gf_halves, const F4* rho_pw, const u32* d_rho_pow) {
+    typedef typename C::Fr FrP;
+    typedef host::Fld<FrP> S;
+    hipStream_t st = ctx->stream;
+    const size_t W = (size_t)ctx->shard_world, r = (size_t)ctx->shard_rank;
+    const int w = ipa_lg2(W);
+    const size_t n_loc = N / W;
+    size_t S_glob = std::max<size_t>(std::max<size_t>(ctx->tune_ipa_freeze_len, W), 2);   // global length at which the ranks gather
+    { size_t p = 1; while (p < S_glob) p <<= 1; S_glob = p; }
+    const size_t S_loc = S_glob / W;
+    // this rank's slices (the generator tables are read in place: no full working copy)
+    BPCHK(ctx->cyc_a.ensure(std::max(n_loc, S_glob) * 32)); BPCHK(ctx->cyc_b.ensure(std::max(n_loc, S_glob) * 32));
+    BPCHK(ctx->cyc_Gf.ensure(n_loc * 32)); BPCHK(ctx->cyc_Hf.ensure(n_loc * 32));
+    BPCHK(ctx->ipa_G.ensure(std::max(n_loc, S_glob) * 64)); BPCHK(ctx->ipa_H.ensure(std::max(n_loc, S_glob) * 64));
+    const u32 gb = (u32)((n_loc + 255) / 256);
+    hipLaunchKernelGGL(k_cyclic_gather<Blk32>, dim3(gb), dim3(256), 0, st, d_a, ctx->cyc_a.as<u32>(), (u32)n_loc, (u32)r, (u32)W);
+    hipLaunchKernelGGL(k_cyclic_gather<Blk32>, dim3(gb), dim3(256), 0, st, d_b, ctx->cyc_b.as<u32>(), (u32)n_loc, (u32)r, (u32)W);
+    hipLaunchKernelGGL(k_cyclic_gather<Blk32>, dim3(gb), dim3(256), 0, st, d_Gf, ctx->cyc_Gf.as<u32>(), (u32)n_loc, (u32)r, (u32)W);
+    hipLaunchKernelGGL(k_cyclic_gather<Blk32>, dim3(gb), dim3(256), 0, st, d_Hf, ctx->cyc_Hf.as<u32>(), (u32)n_loc, (u32)r, (u32)W);
+    hipLaunchKernelGGL(k_cyclic_gather<Blk64>, dim3(gb), dim3(256), 0, st, d_Gtab, ctx->ipa_G.as<u32>(), (u32)n_loc, (u32)r, (u32)W);
+    hipLaunchKernelGGL(k_cyclic_gather<Blk64>, dim3(gb), dim3(256), 0, st, d_Htab, ctx->ipa_H.as<u32>(), (u32)n_loc, (u32)r, (u32)W);
+    HIPCHK(hipGetLastError());
+    // local geometric hint: H_factors[r + j*W] = rho^r * (rho^W)^j * G_factors: tables of rho^W = the global tables shifted by lg W
+    F4 rho_loc[64];
+    const bool geo = gf_halves && rho_pw && d_rho_pow;
+    if (geo) for (int k = 0; k < 32; k++) { rho_loc[k] = k + w < 32 ? rho_pw[k + w] : S::one(); rho_loc[32 + k] = k + w < 32 ? rho_pw[32 + k + w] : S::one(); }
+    IpaState s;
+    BPCHK(ipa_begin_dev<C>(ctx, s, d_Q, ctx->cyc_Gf.as<u32>(), ctx->cyc_Hf.as<u32>(), ctx->ipa_G.as<u32>(), ctx->ipa_H.as<u32>(), ctx->cyc_a.as<u32>(),
+                           ctx->cyc_b.as<u32>(), n_loc, gf_halves, geo ? rho_loc : nullptr, geo ? d_rho_pow + (size_t)w * 8 : nullptr, false));
+    s.msm_mode = 2;
+    F4 rho_r = S::one(), rho_mr = S::one();   // rho^rank, rho^-rank
+    if (geo) for (int k = 0; k < w; k++) if ((r >> k) & 1) { rho_r = S::mul(rho_r, rho_pw[32 + k]); rho_mr = S::mul(rho_mr, rho_pw[k]); }
+    s.geo_k0 = rho_r; s.have_k0 = geo;
+    while (s.n > S_loc) {
+        uint64_t Lw[8], Rw[8], uw[4];
+        BPCHK(ipa_round_lr<C>(ctx, s, Lw, Rw));
+        memcpy(L_out + 8 * s.round, Lw, 64); memcpy(R_out + 8 * s.round, Rw, 64);
+        int rc = challenge(Lw, Rw, uw);
+        if (rc) { g_err = "ipa_create: challenge callback failed"; return rc < 0 ? rc : BP_E_ARG; }
+        BPCHK(ipa_round_fold<C>(ctx, s, uw));
+    }
+    // gather: [a | b | G | H] of the S_loc local elements, ark layouts, from every rank; global index = rank + j * W
+    const size_t m = s.n;   // == S_loc
+    const size_t per = m * (32 + 32 + 64 + 64);
+    std::vector<host::u8> send(per), recv(per * W);
+    {
+        const u32 g2 = (u32)((m + 255) / 256);
+        BPCHK(ctx->io_out.ensure(per));
+        u32* o = ctx->io_out.as<u32>();
+        hipLaunchKernelGGL(k_scalars_export<FrP>, dim3(g2), dim3(256), 0, st, s.d_a, o, (u32)m);
+        hipLaunchKernelGGL(k_scalars_export<FrP>, dim3(g2), dim3(256), 0, st, s.d_b, o + m * 8, (u32)m);
+        hipLaunchKernelGGL(k_points_dev_to_ark<C>, dim3(g2), dim3(256), 0, st, s.d_G, o + m * 16, (u32)m);
+        hipLaunchKernelGGL(k_points_dev_to_ark<C>, dim3(g2), dim3(256), 0, st, s.d_H, o + m * 32, (u32)m);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(send.data(), o, per, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    { const int rc = ctx->gather_cb(ctx->gather_user, send.data(), per, recv.data()); if (rc) { g_err = "ipa: the all-gather callback failed"; return rc < 0 ? rc : BP_E_ARG; } }
+    std::vector<F4> ga(S_glob), gbv(S_glob);
+    std::vector<A4> gG(S_glob), gH(S_glob);
+    for (size_t rr = 0; rr < W; rr++) {
+        const host::u8* blk = recv.data() + rr * per;
+        for (size_t j = 0; j < m; j++) {
+            const size_t i = rr + j * W;
+            memcpy(&ga[i], blk + j * 32, 32); memcpy(&gbv[i], blk + m * 32 + j * 32, 32);
+            memcpy(&gG[i], blk + m * 64 + j * 64, 64); memcpy(&gH[i], blk + m * 128 + j * 64, 64);
+        }
+    }
+    BPCHK(upload_scalars<C>(ctx, ctx->cyc_a.as<u32>(), ga.data(), S_glob));
+    BPCHK(upload_scalars<C>(ctx, ctx->cyc_b.as<u32>(), gbv.data(), S_glob));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_G.p, gG.data(), S_glob * 64, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->ipa_H.p, gH.data(), S_glob * 64, hipMemcpyHostToDevice, st));
+    BPCHK(bp_points_import(ctx, ctx->ipa_G.p, ctx->ipa_G.p, S_glob));
+    BPCHK(bp_points_import(ctx, ctx->ipa_H.p, ctx->ipa_H.p, S_glob));
+    // the tail: generators frozen as gathered, their pending factors as per-element coefficients.  In the global index the
+    // geometric factor is K_common * rho^i with K_common = (this rank's K) * rho^-rank — the same on every rank.
+    IpaState t;
+    BPCHK(ipa_begin_dev<C>(ctx, t, d_Q, nullptr, nullptr, ctx->ipa_G.as<u32>(), ctx->ipa_H.as<u32>(), ctx->cyc_a.as<u32>(), ctx->cyc_b.as<u32>(), S_glob, nullptr, nullptr,
+                           nullptr, false));
+    BPCHK(ctx->ipa_sL.ensure((2 * S_glob + 1) * 32)); BPCHK(ctx->ipa_sR.ensure((2 * S_glob + 1) * 32));
+    BPCHK(ctx->ipa_part.ensure(((S_glob + 255) / 256 + 1) * 64));
+    t.round = s.round; t.first = false; t.msm_mode = 0;
+    BPCHK(ctx->ipa_cG.ensure(S_glob * 32)); BPCHK(ctx->ipa_cH.ensure(S_glob * 32));
+    t.d_cG = ctx->ipa_cG.as<u32>(); t.d_cH = ctx->ipa_cH.as<u32>();
+    const F4 kH = s.h_geo ? S::mul(s.gamma_H, rho_mr) : s.gamma_H;
+    hipLaunchKernelGGL(k_ipa_freeze_init<C>, dim3((u32)((S_glob + 255) / 256)), dim3(256), 0, st, t.d_cG, t.d_cH, (u32)S_glob, s.pending ? (s.h_geo ? 2 : 1) : 0,
+                       words_of<S>(s.gamma_G), words_of<S>(kH), d_rho_pow);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));   // ga .. gH are locals
+    t.frozen = true; t.n0 = S_glob;
+    while (t.n != 1) {
+        uint64_t Lw[8], Rw[8], uw[4];
+        BPCHK(ipa_round_lr<C>(ctx, t, Lw, Rw));
+        memcpy(L_out + 8 * t.round, Lw, 64); memcpy(R_out + 8 * t.round, Rw, 64);
+        int rc = challenge(Lw, Rw, uw);
+        if (rc) { g_err = "ipa_create: challenge callback failed"; return rc < 0 ? rc : BP_E_ARG; }
+        BPCHK(ipa_round_fold<C>(ctx, t, uw));
+    }
+    return ipa_finish_dev<C>(ctx, t, a_out, b_out);
+}
+// whether a sharded prover can partition an IPA of padded size N this way
+static inline bool ipa_cyclic_applies(const bp_ctx* ctx, size_t N) {
+    const size_t W = (size_t)ctx->shard_world;
+    if (W <= 1 || !ctx->gather_cb || (W & (W - 1)) || N < ctx->tune_cyclic_min) return false;
+    size_t S_glob = std::max<size_t>(std::max<size_t>(ctx->tune_ipa_freeze_len, W), 2);
+    { size_t p = 1; while (p < S_glob) p <<= 1; S_glob = p; }
+    return N >= 2 * S_glob && N / W >= 2;   // at least one partitioned round
 }
 
 // uploads the host vectors of an IPA instance into the ctx's working buffers (engine layouts)
@@ -997,6 +1136,55 @@ static int cs_batch_verify(bp_ctx* c, size_t count, bp_cs* const* vs, const uint
     return rc;
 }
 
+// ---- debug hooks for the reference-held constants (src/util.rs:147-166, src/inner_product_proof.rs:556-562) ----
+// out[i] = x^i for i < n, through pow_table — the device function with which the prover / verifier kernels form y^i, y^-i and z^q
+// (the reference's exp_iter, util.rs:55-58).  xtab: x^(2^k), k < 32, resident words.
+template <class F> __global__ void k_dbg_exp_iter(const u32* __restrict__ xtab, u32 n, u32* __restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    fe_store_ark<F>(w, pow_table<F>(xtab, i));
+    store_words8(out + (size_t)i * 8, w);
+}
+template <class C> static int dbg_exp_iter(bp_ctx* ctx, const uint64_t* x, size_t n, uint64_t* out) {
+    typedef host::Fld<typename C::Fr> S;
+    F4 tab[32]; memcpy(tab[0].v, x, 32);
+    for (int k = 1; k < 32; k++) tab[k] = S::sqr(tab[k - 1]);
+    BPCHK(ctx->r_ypow.ensure(64 * 32)); BPCHK(ctx->io_out.ensure(std::max<size_t>(n, 1) * 32));
+    BPCHK(upload_scalars<C>(ctx, ctx->r_ypow.as<u32>(), tab, 32));
+    hipLaunchKernelGGL(k_dbg_exp_iter<typename C::Fr>, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->r_ypow.as<u32>(), (u32)n, ctx->io_out.as<u32>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, ctx->io_out.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+}
+// <a, b> over the scalar field with the kernels InnerProductProof::create uses for c_L = <a_L, b_R> (k_ipa_scalars +
+// k_ipa_ip_finish; inner_product_proof.rs:83-84, 390-399): the inputs are laid out as a || 0 and 0 || b, so c_L = <a, b>, c_R = 0.
+template <class C> static int dbg_inner_product(bp_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    typedef host::Fld<typename C::Fr> S;
+    hipStream_t st = ctx->stream;
+    std::vector<F4> av(2 * n, S::zero()), bv(2 * n, S::zero()), ones(2 * n, S::one());
+    memcpy(av.data(), a, n * 32); memcpy(bv.data() + n, b, n * 32);
+    BPCHK(ctx->ipa_a.ensure(2 * n * 32)); BPCHK(ctx->ipa_b.ensure(2 * n * 32)); BPCHK(ctx->ipa_Gf.ensure(2 * n * 32)); BPCHK(ctx->ipa_Hf.ensure(2 * n * 32));
+    BPCHK(upload_scalars<C>(ctx, ctx->ipa_a.as<u32>(), av.data(), 2 * n)); BPCHK(upload_scalars<C>(ctx, ctx->ipa_b.as<u32>(), bv.data(), 2 * n));
+    BPCHK(upload_scalars<C>(ctx, ctx->ipa_Gf.as<u32>(), ones.data(), 2 * n)); BPCHK(upload_scalars<C>(ctx, ctx->ipa_Hf.as<u32>(), ones.data(), 2 * n));
+    const u32 gb = (u32)((n + 255) / 256);
+    BPCHK(ctx->ipa_sL.ensure((2 * n + 1) * 32)); BPCHK(ctx->ipa_sR.ensure((2 * n + 1) * 32)); BPCHK(ctx->ipa_part.ensure((size_t)gb * 64));
+    u32* sL = ctx->ipa_sL.as<u32>();
+    u32* sR = ctx->ipa_sR.as<u32>();
+    Words8 zero; memset(&zero, 0, sizeof zero);
+    hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, ctx->ipa_a.as<u32>(), ctx->ipa_b.as<u32>(), ctx->ipa_Gf.as<u32>(), ctx->ipa_Hf.as<u32>(), 0, (u32)n, sL, sR,
+                       ctx->ipa_part.as<u32>(), 0, zero, zero, (const u32*)nullptr);
+    hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8);
+    HIPCHK(hipGetLastError());
+    uint64_t canon[4];
+    HIPCHK(hipMemcpyAsync(canon, sL + 2 * n * 8, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    F4 r = S::from_canon(canon);
+    memcpy(out, r.v, 32);
+    return BP_OK;
+}
+
 // ---- helpers of the bp_cs entry points (templates cannot live inside extern "C") ----
 #define CS_DISPATCH(h, expr0, expr1) ((h)->curve == 0 ? (expr0) : (expr1))
 // ---- r1cs::Prover / Verifier / ConstraintSystem for a caller's own gadgets -----------------------------------------------------
@@ -1153,7 +1341,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
-                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab};
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->cyc_a, &c->cyc_b, &c->cyc_Gf, &c->cyc_Hf, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab};
     c->templates.clear();
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -1170,9 +1358,15 @@ int bp_ctx_set_window_shard(bp_ctx* c, int rank, int world, bp_point_reduce_cb c
     c->shard_rank = rank; c->shard_world = world; c->shard_cb = cb; c->shard_user = user;
     return BP_OK;
 }
+int bp_ctx_set_shard_allgather(bp_ctx* c, bp_allgather_cb cb, void* user) {
+    if (!c) return BP_E_ARG;
+    c->gather_cb = cb; c->gather_user = user;
+    return BP_OK;
+}
 int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
     if (!c) return BP_E_ARG;
     switch (knob) {
+        case BP_TUNE_CYCLIC_MIN: c->tune_cyclic_min = (size_t)value; return BP_OK;
         case BP_TUNE_FOLD_BATCH_MIN: c->tune_fold_batch_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_BIN_MIN: c->tune_msm_bin_min = (size_t)value; return BP_OK;
         case BP_TUNE_IPA_FREEZE_LEN: c->tune_ipa_freeze_len = (size_t)value; return BP_OK;
@@ -1700,6 +1894,16 @@ int bp_ctx_reset_profiling(bp_ctx* c) {
     return BP_OK;
 }
 
+int bp_debug_exp_iter(bp_ctx* c, const uint64_t x[4], size_t n, uint64_t* out) {
+    if (!c || !x || (n && !out) || n >= ((size_t)1 << 31)) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? dbg_exp_iter<Secq>(c, x, n, out) : dbg_exp_iter<Zorro>(c, x, n, out);
+}
+int bp_debug_inner_product(bp_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
+    if (!c || !a || !b || !out || !n || n >= ((size_t)1 << 30)) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return c->curve == 0 ? dbg_inner_product<Secq>(c, a, b, n, out) : dbg_inner_product<Zorro>(c, a, b, n, out);
+}
 int bp_debug_field_op(bp_ctx* c, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     if (!c || !a || !b || !out || field < 0 || field > 3) return BP_E_ARG;
     HIPCHK(hipSetDevice(c->device));

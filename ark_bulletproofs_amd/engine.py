@@ -117,6 +117,28 @@ class Engine:
         self._shard_cb = _POINT_REDUCE_CB(cb)   # keep the thunk alive as long as the mode is on
         check(lib().bp_ctx_set_window_shard(self.ctx, int(rank), int(world), self._shard_cb, None), "bp_ctx_set_window_shard")
 
+    def set_shard_allgather(self, gather_fn=None):
+        """second collective of the sharded mode (bp_ctx_set_shard_allgather): gather_fn(block: uint8 array) -> (world, len) uint8
+        array in rank order.  With it the prover partitions the inner-product argument index-cyclically across the ranks."""
+        if gather_fn is None:
+            check(lib().bp_ctx_set_shard_allgather(self.ctx, None, None), "bp_ctx_set_shard_allgather")
+            self._gather_cb = None
+            return
+        errs = self._gather_errors = []
+
+        def cb(_user, send, nbytes, recv):
+            try:
+                blk = np.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=np.uint8)
+                out = np.ascontiguousarray(gather_fn(blk.copy()), dtype=np.uint8).reshape(-1)
+                C.memmove(recv, out.ctypes.data, out.nbytes)
+                return 0
+            except Exception as e:  # never unwind through C
+                errs.append(e)
+                return 1
+
+        self._gather_cb = _ALLGATHER_CB(cb)
+        check(lib().bp_ctx_set_shard_allgather(self.ctx, self._gather_cb, None), "bp_ctx_set_shard_allgather")
+
     def set_tuning(self, knob, value):
         """knob: 0 fold-batch minimum lanes, 1 MSM two-level-sort minimum terms (include/arkbp.h BP_TUNE_*)"""
         check(lib().bp_ctx_set_tuning(self.ctx, int(knob), C.c_uint64(int(value))), "bp_ctx_set_tuning")
@@ -150,6 +172,7 @@ class Engine:
 
 # ---- InnerProductProof::create ---------------------------------------------------------------------
 _POINT_REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64))
+_ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _CHALLENGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
 
@@ -746,3 +769,20 @@ def transcript_from_state(state):
     t = HostTranscript(b"")
     check(lib().bp_transcript_import_state(t.h, bytes(state)), "bp_transcript_import_state")
     return t
+
+
+def _debug_exp_iter(self, x, n):
+    out = np.zeros((n, 4), dtype=np.uint64)
+    check(lib().bp_debug_exp_iter(self.ctx, ptr(np.ascontiguousarray(x, dtype=np.uint64).reshape(4)), C.c_size_t(n), ptr(out)), "bp_debug_exp_iter")
+    return out
+
+
+def _debug_inner_product(self, a, b):
+    a, b = u64arr(a, 4), u64arr(b, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib().bp_debug_inner_product(self.ctx, ptr(a), ptr(b), C.c_size_t(len(a)), ptr(out)), "bp_debug_inner_product")
+    return out
+
+
+Engine.debug_exp_iter = _debug_exp_iter
+Engine.debug_inner_product = _debug_inner_product

@@ -122,10 +122,13 @@ def window_sharded_msm(curve, n, local_msm_windows, window_count, points_sum, ra
     return points_sum(curve, allgather_points(part, group, device))
 
 
-def enable_window_sharding(engine, curve, points_sum, rank, world, group=None, device=None, allgather=None):
+def enable_window_sharding(engine, curve, points_sum, rank, world, group=None, device=None, allgather=None, cyclic_ipa=True):
     """north_star's partition for one large proof: every rank runs the same prover / verifier call on the same statement, every
     MSM inside accumulates only this rank's Pippenger windows, and the partial points are summed here (all-gather of one
-    64-byte point per rank + host point-reduce).  All ranks end with the identical proof."""
+    64-byte point per rank + host point-reduce).  With cyclic_ipa (and a power-of-two world) the inner-product argument is
+    partitioned as well: rank r folds only the elements i = r mod world (bp_ctx_set_shard_allgather), the L / R of a round are
+    sums of per-rank partial MSMs through the same point-reduce, and the last ~1024 elements are all-gathered once.
+    All ranks end with the identical proof."""
     if allgather is None:
         def allgather(arr):
             return allgather_words(arr, group, device)
@@ -133,7 +136,11 @@ def enable_window_sharding(engine, curve, points_sum, rank, world, group=None, d
     def reduce_fn(xy):
         return points_sum(curve, allgather(xy).reshape(-1, 8))
 
+    def gather_bytes(blk):
+        return allgather(np.ascontiguousarray(blk).view(np.uint64)).view(np.uint8)     # block sizes are multiples of 32 bytes
+
     engine.set_window_shard(rank, world, reduce_fn if world > 1 else None)
+    engine.set_shard_allgather(gather_bytes if (world > 1 and cyclic_ipa) else None)
 
 
 def sharded_batch_verify(curve, instances, local_batch_verify, points_sum, rank, world, group=None, device=None):

@@ -89,6 +89,14 @@ int bp_msm_gens(bp_ctx* ctx, int use_G, int use_H, size_t off, size_t n, const u
  * (bp_msm_dev_windows) are not affected. */
 typedef int (*bp_point_reduce_cb)(void* user, uint64_t xy[8]);
 int bp_ctx_set_window_shard(bp_ctx* ctx, int rank, int world, bp_point_reduce_cb cb, void* user);
+/* Optional second collective of the sharded mode: cb(user, send, bytes, recv) must fill recv with the `world` ranks' `bytes`-long
+ * blocks in rank order (an all-gather) and return 0.  With it (and a power-of-two world) the prover also partitions the
+ * inner-product argument: rank r keeps the elements i = r + j*world of a, b, G, H (src/inner_product_proof.rs:139-156,216-225 fold
+ * element i with i + n/2 — both on the same rank), a round's L and R are sums of per-rank partial MSMs through the point-reduce
+ * callback, and when the vectors are down to the frozen-tail length (BP_TUNE_IPA_FREEZE_LEN) the ranks all-gather the rest once
+ * and finish replicated.  Every fold launch then does 1/world of the single-GPU work; proofs stay byte-identical on every rank. */
+typedef int (*bp_allgather_cb)(void* user, const void* send, size_t bytes, void* recv);
+int bp_ctx_set_shard_allgather(bp_ctx* ctx, bp_allgather_cb cb, void* user);
 
 /* ---- InnerProductProof::create -------------------------------------------------------------------
  * Replaces `InnerProductProof::create(transcript, &Q, &G_factors, &H_factors, G_vec, H_vec, a_vec, b_vec)`
@@ -338,6 +346,7 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
 #define BP_TUNE_MSM_BIN_MIN 1
 #define BP_TUNE_IPA_FREEZE_LEN 2
 #define BP_TUNE_MSM_WSUM_MIN 3
+#define BP_TUNE_CYCLIC_MIN 4   /* padded size from which a sharded prover partitions the IPA index-cyclically (default 2^14) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 
 /* The O(N) part of `Verifier::verification_scalars` (src/r1cs/verifier.rs:465-514, s from inner_product_proof.rs:279-311) for a
@@ -354,6 +363,12 @@ int bp_r1cs_verification_gh(bp_ctx* ctx, size_t n, size_t n1, const uint64_t* wL
 /* ---- unit-test hooks: one field / group operation per element on the GPU -------------------------- */
 /* field: 2*curve + (0 base field | 1 scalar field); op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inv */
 int bp_debug_field_op(bp_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* the reference's two fixed-value unit tests, through the kernels' own code paths: out[i] = x^i, i < n (`exp_iter`, src/util.rs:55-58,
+ * test :147-157) by the power-table routine the prover / verifier kernels use; and <a, b> over the ctx's scalar field
+ * (`inner_product`, src/inner_product_proof.rs:390-399, tests :556-562 and src/util.rs:160-166) by the kernels that form
+ * c_L = <a_L, b_R> in InnerProductProof::create.  Inputs / outputs: ark Montgomery words. */
+int bp_debug_exp_iter(bp_ctx* ctx, const uint64_t x[4], size_t n, uint64_t* out);
+int bp_debug_inner_product(bp_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);
 /* ark-serialize compressed SW points (33 bytes each: x LE || flag byte) -> affine, on the GPU (the square roots of
  * `R1CSProof::from_bytes`, src/r1cs/proof.rs:83-91); out_ok[i] = 0 for malformed or off-curve encodings */
 int bp_debug_decompress(bp_ctx* ctx, const uint8_t* compressed33, size_t n, uint64_t* out_xy, uint32_t* out_ok);

@@ -86,6 +86,16 @@ void orc_fe_rand(int fid, const u8* seed, size_t count, u64* out) {
     for (size_t i = 0; i < count; i++) *(Fe*)(out + 4 * i) = fe_rand(field_of(fid), r);
 }
 
+// util::exp_iter (src/util.rs:55-58): 1, x, x^2, ... by repeated multiplication, as the reference iterates; and
+// inner_product (src/inner_product_proof.rs:390-399).  The reference pins both: exp_iter(2) -> 1,2,4,8 (util.rs:147-157),
+// inner_product([1,2,3,4],[2,3,4,5]) = 40 over secq256k1's Fr (util.rs:160-166) and secp256k1's Fr = secq256k1's Fq (:556-562).
+void orc_exp_iter(int fid, const u64* x, size_t n, u64* out) {
+    const Field& F = field_of(fid);
+    Fe cur = F.R1;
+    for (size_t i = 0; i < n; i++) { *(Fe*)(out + 4 * i) = cur; F.mul(cur, cur, *(const Fe*)x); }
+}
+void orc_inner_product(int fid, const u64* a, const u64* b, size_t n, u64* out) { *(Fe*)out = inner_product(field_of(fid), (const Fe*)a, (const Fe*)b, n); }
+
 // ---- byte primitives -----------------------------------------------------------------------
 void orc_sha3_512(const u8* msg, size_t n, u8* out) { sha3_512(out, msg, n); }
 void orc_chacha20_words(const u8* seed, size_t nwords, u32* out) {

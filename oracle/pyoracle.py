@@ -490,3 +490,37 @@ def batch_verify_cs(curve, verifiers, proofs, gens_cap, alphas):
         if v._cb_errors:
             raise v._cb_errors[0]
     return rc, pt
+
+
+def exp_iter(f, x, n):
+    out = np.zeros((n, 4), dtype=np.uint64)
+    lib().orc_exp_iter(f, _p(np.ascontiguousarray(x, dtype=np.uint64)), C.c_size_t(n), _p(out))
+    return out
+
+
+def inner_product(f, a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    out = _u64(4)
+    lib().orc_inner_product(f, _p(a), _p(b), C.c_size_t(len(a)), _p(out))
+    return out
+
+
+def batch_verify_point(curve, instances, gens_cap, alpha_seed):
+    """batch_verify over scenario instances [(scenario, params, proof, commitments, publics)]: (status, mega-check point)"""
+    n = len(instances)
+    scen = (C.c_int * n)(*[i[0] for i in instances])
+    prm = np.zeros((n, 8), dtype=np.uint64)
+    for k, i in enumerate(instances):
+        prm[k, : len(i[1])] = np.array(i[1], dtype=np.uint64)
+    proofs = b"".join(i[2] for i in instances)
+    plens = (C.c_size_t * n)(*[len(i[2]) for i in instances])
+    cm_l = [np.asarray(i[3], dtype=np.uint64).reshape(-1, 8) for i in instances]
+    cms = np.ascontiguousarray(np.concatenate(cm_l))
+    ms = (C.c_size_t * n)(*[len(c) for c in cm_l])
+    pubs_l = [np.asarray(i[4], dtype=np.uint64).reshape(-1, 4) for i in instances]
+    pubs = np.ascontiguousarray(np.concatenate(pubs_l + [np.zeros((1, 4), dtype=np.uint64)]))
+    npubs = (C.c_size_t * n)(*[len(p) for p in pubs_l])
+    pt = _u64(8)
+    rc = lib().orc_batch_verify_point(curve, C.c_size_t(n), scen, _p(prm), C.c_size_t(gens_cap), proofs, plens, _p(cms), ms, _p(pubs), npubs, bytes(alpha_seed), _p(pt))
+    return rc, pt

@@ -305,6 +305,9 @@ def _wshard_worker(rank, world, port, q):
             def set_window_shard(self, r, w, fn=None):
                 self.args = (r, w, fn)
 
+            def set_shard_allgather(self, fn=None):
+                self.gather = fn
+
         out = {}
         for cv in (0, 1):
             G, _ = O.bp_gens(cv, world + 1)
@@ -316,8 +319,12 @@ def _wshard_worker(rank, world, port, q):
                 full = O.point_add(cv, full, G[i])
             out["sum%d" % cv] = bool(r == rank and w == world and (fn(G[rank]) == full).all())
             out["identity%d" % cv] = bool((fn(np.zeros(8, dtype=np.uint64) if rank else G[0]) == G[0]).all())
+            # the second collective (index-cyclic IPA): byte blocks come back in rank order
+            blk = (np.arange(96, dtype=np.uint8) + 7 * rank).astype(np.uint8)
+            got = np.asarray(fe.gather(blk)).reshape(world, 96)
+            out["gather%d" % cv] = bool(all((got[r2] == (np.arange(96, dtype=np.uint8) + 7 * r2).astype(np.uint8)).all() for r2 in range(world)))
             P.enable_window_sharding(fe, cv, E.host_points_sum, 0, 1)
-            out["off%d" % cv] = fe.args[1] == 1 and fe.args[2] is None
+            out["off%d" % cv] = fe.args[1] == 1 and fe.args[2] is None and fe.gather is None
         dist.barrier()
         q.put((rank, out))
     finally:

@@ -82,15 +82,107 @@ def test_msm_linearity_2pow20(eng):
         d.free()
 
 
-def test_gpu_generator_derivation_matches_host_chain(eng):
-    """BulletproofGens::new on the GPU (device Tonelli-Shanks over the recorded ChaCha20 attempts) against the product's host
-    derivation of the same GeneratorsChain, deep into the chain (indices up to 2^16)"""
+def test_gpu_generator_derivation_matches_oracle_at_depth(eng, oracle):
+    """BulletproofGens::new on the GPU (device Tonelli-Shanks over the recorded ChaCha20 attempts) against the ORACLE's
+    GeneratorsChain (src/generators.rs:71-121, restated sequentially) deep into the chain (all indices up to 2^16), and
+    against the product's own host derivation"""
     from ark_bulletproofs_amd import engine as E
 
     G, H = eng.gens_download(1 << 16)
+    Go, Ho = oracle.bp_gens(0, 1 << 16)
+    assert (G == Go).all() and (H == Ho).all()
     Gh = E.host_derive_generators(0, 0, 0, 1 << 16)
     Hh = E.host_derive_generators(0, 1, 0, 1 << 16)
     assert (G == Gh).all() and (H == Hh).all()
+
+
+def test_cfg4_full_batch_4096_and_failing_check_point(eng, oracle):
+    """BASELINE cfg4 at its real workload: batch_verify of 4096 proofs of 2^14 constraints (256 x 64-bit range proofs, m = 256).
+    Accept; one corrupted proof -> VerificationError.  The oracle replays a 48-instance prefix containing the corrupted one with
+    the same alphas: by linearity (valid instances contribute the identity) the FULL failing batch's mega-check point on the GPU
+    must equal the oracle's point for the prefix."""
+    from ark_bulletproofs_amd import engine as E
+
+    O = oracle
+    distinct = []
+    for i in range(8):
+        pr = eng.prove_scenario(E.SC_MULTI_RANGE, [256, 64, 0], bytes([4, i, 1] + [4] * 29), m_cap=264)
+        distinct.append((E.SC_MULTI_RANGE, [256, 64, 0], pr.proof, pr.commitments, pr.publics))
+    inst = [distinct[i % 8] for i in range(4096)]
+    seed = bytes([5]) * 32
+    rc, _, pt = eng.batch_verify(inst, seed, want_point=True)
+    assert rc == 0 and not pt.any()
+    bad_at = 37
+    sc, prm, proof, cm, pb = inst[bad_at]
+    bad = bytearray(proof)
+    bad[11 * 33 + 40] ^= 8          # t_x_blinding
+    inst[bad_at] = (sc, prm, bytes(bad), cm, pb)
+    rc, _, pt = eng.batch_verify(inst, seed, want_point=True)
+    assert rc == -4 and pt.any()
+    orc, opt = O.batch_verify_point(0, inst[:48], 1 << 14, seed)
+    assert orc == O.E_VERIFICATION
+    assert (pt == opt).all(), "mega-check point of the failing full batch differs from the oracle's"
+    # a second corrupted instance far behind the prefix changes the point
+    sc, prm, proof, cm, pb = inst[3000]
+    bad = bytearray(proof)
+    bad[-1] ^= 1
+    inst[3000] = (sc, prm, bytes(bad), cm, pb)
+    rc, _, pt2 = eng.batch_verify(inst, seed, want_point=True)
+    assert rc in (-4, -6)
+    if rc == -4:
+        assert (pt2 != pt).any()
+
+
+@pytest.mark.parametrize("curve", [0, 1], ids=["secq256k1", "zorro"])
+def test_cfg5_prove_verify_2pow22(curve):
+    """BASELINE cfg5's size on one GPU: a 2^22-constraint square-chain proof (generator tables 2 x 256 MiB resident), prove ->
+    verify -> tamper, on secq256k1 and on zorro"""
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+
+    N = 1 << 22
+    e = A.Engine(curve=curve)
+    try:
+        e.gens_derive(N)
+        st = E.Statement(curve, E.SC_SQUARE_CHAIN, [N, 0], bytes([3 + curve]) * 32)
+        commits, pubs, nm, nq = st.info(m_cap=8)
+        assert nm == N and nq == 2 * N + 1
+        proof, _ = st.prove(e)
+        st.free()
+        assert len(proof) == 539 + 66 * 22
+        assert e.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], proof, commits, pubs) == 0
+        bad = bytearray(proof)
+        bad[2 * 33 + 7] ^= 1          # S1's x coordinate: off the curve (FormatError) or another point (VerificationError)
+        assert e.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], bytes(bad), commits, pubs) in (-4, -6)
+        bad = bytearray(proof)
+        bad[-33] ^= 1                 # ipp a
+        assert e.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], bytes(bad), commits, pubs) == -4
+        wrong = pubs.copy()
+        wrong[0, 1] ^= np.uint64(1)
+        assert e.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], proof, commits, wrong) == -4
+    finally:
+        e.close()
+
+
+def test_batch_of_600_distinct_statements(eng):
+    """one template per STRUCTURE, not per statement: 600 distinct-witness proofs (square chains with 600 different public outputs,
+    range proofs of 64 different values) in one batch — more than the template cache (64) and more than a 512-block"""
+    from ark_bulletproofs_amd import engine as E
+
+    inst = []
+    for i in range(536):
+        pr = eng.prove_scenario(E.SC_SQUARE_CHAIN, [8, 0], bytes([i & 255, i >> 8, 7] + [2] * 29), m_cap=8)
+        inst.append((E.SC_SQUARE_CHAIN, [8, 0], pr.proof, pr.commitments, pr.publics))
+    for i in range(64):
+        pr = eng.prove_scenario(E.SC_RANGE, [16, 1000 + i], bytes([i, 9] + [2] * 30), m_cap=8)
+        inst.append((E.SC_RANGE, [16, 1000 + i], pr.proof, pr.commitments, pr.publics))
+    assert len({i[4].tobytes() for i in inst[:536]}) > 500       # the public outputs really differ
+    rc, _ = eng.batch_verify(inst, bytes([6]) * 32)
+    assert rc == 0
+    sc, prm, proof, cm, pb = inst[530]
+    inst[530] = (sc, prm, proof, cm, inst[529][4])              # another statement's public output
+    rc, _ = eng.batch_verify(inst, bytes([6]) * 32)
+    assert rc == -4
 
 
 def test_cfg3_shuffle_statement_full_size():

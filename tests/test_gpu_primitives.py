@@ -299,3 +299,30 @@ def test_msm_over_resident_generator_tables(oracle):
             e.msm_gens(41, sc[:82], off=260)
         assert ei.value.code == -5
         e.close()
+
+
+def test_reference_held_constants_on_gpu(eng, oracle):
+    """exp_iter(2) -> 1, 2, 4, 8 (src/util.rs:147-157) and inner_product = 40 (src/util.rs:160-166, src/inner_product_proof.rs:
+    556-562) through the kernels' own power-table and inner-product code; plus longer runs against the oracle"""
+    O = oracle
+    e, curve = eng, eng.curve
+    fr = O.fid(curve, True)
+    two = O.fe_from_int(fr, 2)
+    got = e.debug_exp_iter(two, 4)
+    for i, want in enumerate([1, 2, 4, 8]):
+        assert (got[i] == O.fe_from_int(fr, want)).all()
+    x = O.fe_rand(fr, bytes([8]) * 32, 1)[0]
+    assert (e.debug_exp_iter(x, 1000) == O.exp_iter(fr, x, 1000)).all()
+    a = [O.fe_from_int(fr, v) for v in (1, 2, 3, 4)]
+    b = [O.fe_from_int(fr, v) for v in (2, 3, 4, 5)]
+    assert (e.debug_inner_product(a, b) == O.fe_from_int(fr, 40)).all()
+    va, vb = O.fe_rand(fr, bytes([9]) * 32, 777), O.fe_rand(fr, bytes([10]) * 32, 777)
+    assert (e.debug_inner_product(va, vb) == O.inner_product(fr, va, vb)).all()
+    # secp256k1's Fr (= secq256k1's base field, the field of the reference's second inner_product test): GPU field ops
+    if curve == 0:
+        fq = O.fid(0, False)
+        A = np.array([O.fe_from_int(fq, v) for v in (1, 2, 3, 4)])
+        B = np.array([O.fe_from_int(fq, v) for v in (2, 3, 4, 5)])
+        prod = e.debug_field_op(fq, 0, A, B)
+        s = e.debug_field_op(fq, 1, e.debug_field_op(fq, 1, prod[0:1], prod[1:2]), e.debug_field_op(fq, 1, prod[2:3], prod[3:4]))
+        assert (s[0] == O.fe_from_int(fq, 40)).all()

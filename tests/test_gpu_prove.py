@@ -158,6 +158,11 @@ def test_window_sharded_prover_ranks_as_threads(oracle, world):
                     return res
 
                 P.enable_window_sharding(e, cv, E.host_points_sum, rank, world, allgather=allgather)
+                # world 2: the prover also partitions the inner-product argument index-cyclically (thresholds lowered so that the
+                # 128- and 32-element IPAs of these statements take that path: cyclic rounds down to 4 elements, gather, frozen tail);
+                # world 3 is not a power of two: folds stay replicated
+                e.set_tuning(4, 16)   # BP_TUNE_CYCLIC_MIN
+                e.set_tuning(2, 4)    # BP_TUNE_IPA_FREEZE_LEN
                 got = []
                 for (sc, prm), ref in zip(cases, refs):
                     pr = e.prove_scenario(sc, prm, SEED, m_cap=128)
@@ -182,3 +187,63 @@ def test_window_sharded_prover_ranks_as_threads(oracle, world):
         for r in range(world):
             for (proof, rc, rc_bad), ref in zip(out[r], refs):
                 assert proof == ref.proof and rc == 0 and rc_bad in (-4, -6)
+
+
+def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
+    """cfg5's partition at full-size kernels with the default thresholds: a 2^16-constraint proof by two ranks (threads, one Engine
+    each on the same GPU): Pippenger windows of the commitment MSMs partitioned, the IPA index-cyclic (32768 elements per rank,
+    gather at 1024), the verifier's mega-check window-sharded.  Both ranks must emit exactly the single-GPU proof."""
+    import threading
+
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+    from ark_bulletproofs_amd import parallel as P
+
+    N, world, cv = 1 << 16, 2, 0
+    cases = [(3, [N, 0]), (0, [(N // 2) + 1])]      # square chain (geometric H factors, constant G factors) and a 2^16-multiplier shuffle (all phase 2)
+    single = A.Engine(curve=cv)
+    single.gens_derive(N)
+    refs = [single.prove_scenario(sc, prm, SEED, m_cap=N + 16) for sc, prm in cases]
+    for (sc, prm), ref in zip(cases, refs):
+        assert single.verify_scenario(sc, prm, ref.proof, ref.commitments, ref.publics) == 0
+    bar = threading.Barrier(world)
+    slots, out, errors = [None] * world, [None] * world, []
+    big_gathers = [0] * world
+
+    def run(rank):
+        try:
+            e = A.Engine(curve=cv)
+            e.share_gens_from(single)
+
+            def allgather(arr):
+                if np.asarray(arr).size > 8:
+                    big_gathers[rank] += 1       # not a 64-byte point: the IPA's vector gather
+                slots[rank] = np.array(arr, copy=True)
+                bar.wait()
+                res = np.stack(slots)
+                bar.wait()
+                return res
+
+            P.enable_window_sharding(e, cv, E.host_points_sum, rank, world, allgather=allgather)
+            got = []
+            for (sc, prm) in cases:
+                pr = e.prove_scenario(sc, prm, SEED, m_cap=N + 16)
+                got.append((pr.proof, e.verify_scenario(sc, prm, pr.proof, pr.commitments, pr.publics)))
+            out[rank] = got
+            P.enable_window_sharding(e, cv, E.host_points_sum, 0, 1)
+            e.close()
+        except Exception as ex:
+            errors.append(ex)
+            bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for r in range(world):
+        for (proof, rc), ref in zip(out[r], refs):
+            assert proof == ref.proof and rc == 0
+        assert big_gathers[r] == len(cases), "the index-cyclic IPA path was not taken"
+    single.close()

@@ -179,3 +179,19 @@ def test_generators_self_consistency(oracle, curve):
         M.CURVES[curve]["q"],
     ) == 1:
         assert (Bb[:4] == x0).all()
+
+
+def test_reference_held_constants(oracle):
+    """the only fixed values the reference's own tests hold on this path: exp_iter(2) -> 1, 2, 4, 8 over secq256k1's Fr
+    (src/util.rs:147-157); inner_product([1,2,3,4], [2,3,4,5]) = 40 over secq256k1's Fr (src/util.rs:160-166) and over
+    ark_secp256k1::Fr — the secp256k1 group order, i.e. secq256k1's BASE field (src/inner_product_proof.rs:556-562)"""
+    O = oracle
+    fr = O.fid(0, True)
+    got = O.exp_iter(fr, O.fe_from_int(fr, 2), 4)
+    for i, want in enumerate([1, 2, 4, 8]):
+        assert (got[i] == O.fe_from_int(fr, want)).all()
+    for f in (O.fid(0, True), O.fid(0, False), O.fid(1, True)):
+        a = [O.fe_from_int(f, v) for v in (1, 2, 3, 4)]
+        b = [O.fe_from_int(f, v) for v in (2, 3, 4, 5)]
+        assert (O.inner_product(f, a, b) == O.fe_from_int(f, 40)).all()
+    assert O.modulus(O.fid(0, False)) == 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141   # secp256k1's group order
