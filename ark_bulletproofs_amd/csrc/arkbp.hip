@@ -81,6 +81,10 @@ struct IpaState {
     // multi-GPU: how the L / R MSMs of this instance treat the ctx's shard mode (see msm_run): -1 = the ctx default (window
     // partition + point-reduce), 2 = this rank's terms are its own slice of the vectors (index-cyclic IPA): all windows, then the
     // point-reduce, 0 = replicated (every rank computes the same small MSM: the frozen tail after the gather)
+    // gens_stride > 0: the working vectors are (a slice of) the ctx's generator tables at round 1: d_G[i] = G[gens_first + i*gens_stride]
+    u32 gens_first = 0, gens_stride = 0;
+    // round 1 may read the generators straight from the ctx's resident tables (no working copy): non-null until the first fold
+    const u32 *d_G_in = nullptr, *d_H_in = nullptr;
     int msm_mode = -1;
     F4 geo_k0;                  // index-cyclic slices: the geometric H factor of local element j is K * rho^(rank + j*world) = (K * geo_k0) * (rho^world)^j
     bool have_k0 = false;
@@ -131,6 +135,10 @@ struct bp_ctx {
     void* gather_user = nullptr;
     size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
     DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
+    // fixed-base tables of the generators for the first fold round (bp_gens_fold_tables; ipa.cuh k_ipa_fold_tab)
+    DevBuf ftab_G, ftab_H;
+    size_t ftab_n = 0;       // bases covered: G[0..ftab_n), H[0..ftab_n)
+    int ftab_w = 0, ftab_nwin = 0;
     IpaState ipa_step;         // bp_ipa_begin .. bp_ipa_finish
     bool ipa_step_active = false;
     u32* h_totals = nullptr;  // pinned
@@ -181,10 +189,13 @@ static MsmPlan msm_plan(size_t n, int bits) {
     return pl;
 }
 
-template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u32* d_scalars, size_t n, int scalars_mont, J4& result,
+template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u32* d_scalars_one, size_t n, int scalars_mont, J4& result,
                                       int w_lo = 0, int w_hi = -1 /* window range for multi-GPU window sharding; default all */,
                                       int shard_mode = -1 /* -1: the ctx's mode (window partition + reduce when world > 1); 0: none (replicated);
-                                                             2: the terms are this rank's own share: all windows, then the point-reduce */) {
+                                                             2: the terms are this rank's own share: all windows, then the point-reduce */,
+                                      const ScalSegs* sseg = nullptr /* the scalars as runs read in place (then d_scalars_one is unused) */) {
+    ScalSegs d_scalars; memset(&d_scalars, 0, sizeof d_scalars);
+    if (sseg) d_scalars = *sseg; else { d_scalars.nseg = 1; d_scalars.ptr[0] = d_scalars_one; d_scalars.start[0] = 0; d_scalars.start[1] = (u32)n; }
     typedef host::Grp<C> G;
     typedef host::Fld<typename C::Fq> F;
     result = G::inf();
@@ -322,7 +333,11 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         HIPCHK(hipGetLastError());
         return BP_OK;
     };
+    static const bool mtrace = getenv("ARKBP_MSM_TRACE") != nullptr;   // host-side phase times of every MSM on stderr
+    const auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_m0 = mtrace ? tnow() : 0;
     BPCHK(front_end(binned));
+    const double t_m1 = mtrace ? tnow() : 0;
     if (binned && ctx->h_totals[NL + 1] != 0) {   // a bin region overflowed (skewed scalars): one-pass slots for every window
         binned = false;
         BPCHK(front_end(false));
@@ -346,6 +361,17 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (K >= nl) { g_err = "msm: bucket population exceeds the reduction depth"; return BP_E_ARG; }
     BPCHK(ctx->lvA.ensure((size_t)tot[1] * 96));
     if (K >= 2) BPCHK(ctx->lvB.ensure((size_t)tot[2] * 96));
+    static const bool accum_wave = getenv("ARKBP_MSM_ACCUM") && !strcmp(getenv("ARKBP_MSM_ACCUM"), "wave");   // A/B: one wavefront per bucket
+    if (accum_wave && !special) {
+        // the bucket sums go straight to the last level's slots (<= 1 per bucket): no tree above
+        ScopedK acc(ctx, BP_K_MSM_ACCUM);
+        hipLaunchKernelGGL(k_msm_accum_wave<C>, dim3((pl.B + 3) / 4), dim3(256), 0, st, segs, entries_ptr, lvl, lvl + Bp1 * K, ctx->lvA.as<u32>(), pl.B,
+                           slotted ? (binned ? 2 : 1) : 0, sp, (u32)pl.NB, ctx->boff.as<u32>());
+        acc.stop();
+        const u32* last_off = lvl + Bp1 * K;
+        if (use_marginals) hipLaunchKernelGGL(k_msm_marginals<C>, dim3(pl.W, pl.c), dim3(256), 0, st, ctx->lvA.as<u32>(), last_off, ctx->Tbuf.as<u32>(), pl);
+        else hipLaunchKernelGGL(k_msm_window_sums<C>, dim3(nblk_ws, pl.W), dim3(256), 0, st, ctx->lvA.as<u32>(), last_off, ctx->Tbuf.as<u32>(), pl, nblk_ws);
+    } else {
     {
         ScopedK acc(ctx, BP_K_MSM_ACCUM);
         hipLaunchKernelGGL(k_msm_accum<C>, dim3((tot[1] + TB - 1) / TB), dim3(TB), 0, st, segs, entries_ptr, lvl, lvl + Bp1, ctx->lvA.as<u32>(), pl.B,
@@ -362,10 +388,13 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     }
     if (use_marginals) hipLaunchKernelGGL(k_msm_marginals<C>, dim3(pl.W, pl.c), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl);
     else hipLaunchKernelGGL(k_msm_window_sums<C>, dim3(nblk_ws, pl.W), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl, nblk_ws);
+    }
     HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tbytes, hipMemcpyDeviceToHost, st));
     total.stop();
+    const double t_m2 = mtrace ? tnow() : 0;
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
+    const double t_m3 = mtrace ? tnow() : 0;
     J4 acc = G::inf();
     const u64* T = (const u64*)ctx->h_T;
     auto add_T = [&](size_t idx) {
@@ -385,6 +414,8 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     }
     (void)sizeof(F);
     result = acc;
+    if (mtrace) fprintf(stderr, "[msm] n=%zu c=%d W=%d K=%d  front(enqueue+sync) %.1f us  back enqueue %.1f us  back wait %.1f us  host tail %.1f us\n", n, pl.c, pl.W, K,
+                        (t_m1 - t_m0) * 1e6, (t_m2 - t_m1) * 1e6, (t_m3 - t_m2) * 1e6, (tnow() - t_m3) * 1e6);
     return finish_sharded(result);
 }
 
@@ -494,7 +525,8 @@ static void naf_masks(const uint64_t k_in[3], bool negate, u32 plus[5], u32 minu
     }
 }
 // t (field element) -> t1 + t2*lambda with short t1, t2; fills the four masks of one vector.  false if a half exceeds 129 bits.
-template <class C> static bool glv_decompose(const F4& t, u32 p1[5], u32 m1[5], u32 p2[5], u32 m2[5]) {
+struct GlvRaw { uint64_t mg1[3], mg2[3]; bool n1, n2; };   // t = (n1 ? -mg1 : mg1) + lambda * (n2 ? -mg2 : mg2)
+template <class C> static bool glv_decompose(const F4& t, u32 p1[5], u32 m1[5], u32 p2[5], u32 m2[5], GlvRaw* raw = nullptr) {
     if constexpr (C::HAS_GLV) {
         typedef host::Fld<typename C::Fr> S;
         uint64_t tc[4]; S::to_canon(tc, t);
@@ -519,11 +551,12 @@ template <class C> static bool glv_decompose(const F4& t, u32 p1[5], u32 m1[5], 
         };
         uint64_t mg1[3], mg2[3]; bool n1, n2;
         if (!split(k1, mg1, n1) || !split(k2, mg2, n2)) return false;
+        if (raw) { memcpy(raw->mg1, mg1, 24); memcpy(raw->mg2, mg2, 24); raw->n1 = n1; raw->n2 = n2; return true; }
         naf_masks(mg1, n1, p1, m1);
         naf_masks(mg2, n2, p2, m2);
         return true;
     } else {
-        (void)t; (void)p1; (void)m1; (void)p2; (void)m2;
+        (void)t; (void)p1; (void)m1; (void)p2; (void)m2; (void)raw;
         return false;
     }
 }
@@ -568,6 +601,92 @@ template <class C> static int launch_uniform_fold(bp_ctx* ctx, u32* d_G, u32* d_
         hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, a, b, which, ff.jac);
     }
     fold_finish_launch<C>(st, ff, d_G, d_H, n, which, lanes);
+    return BP_OK;
+}
+
+// ---- fixed-base tables for the first fold round (ipa.cuh: k_ftab_window, k_ftab_normalize, k_ipa_fold_tab) --------------------
+// signed w-bit digits of a non-negative integer (limbs little-endian, `nl` of them), least significant window first
+static void ftab_recode(const uint64_t* mag, int nl, bool negate, int w, int nwin, unsigned short* e, unsigned long long& negmask) {
+    uint64_t k[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < nl; i++) k[i] = mag[i];
+    const uint64_t full = (uint64_t)1 << w, half = full >> 1;
+    negmask = 0;
+    for (int j = 0; j < nwin; j++) {
+        uint64_t d = k[0] & (full - 1);
+        for (int i = 0; i < 4; i++) k[i] = (k[i] >> w) | (k[i + 1] << (64 - w));
+        k[4] >>= w;
+        bool neg = false;
+        if (d > half) { d = full - d; neg = true; for (int i = 0; i < 5; i++) if (++k[i]) break; }   // digit d - 2^w, carry 1
+        e[j] = (unsigned short)d;
+        if (d && (neg != negate)) negmask |= 1ull << j;
+    }
+}
+template <class C> static int ftab_nwin_for(int w) { return (C::HAS_GLV ? 130 : 256) / w + 1; }
+template <class C> static bool ftab_digits(const bp_ctx* ctx, const F4& t, FtabDigits& d) {
+    typedef host::Fld<typename C::Fr> S;
+    memset(&d, 0, sizeof d);
+    d.nwin = (u32)ctx->ftab_nwin;
+    if (d.nwin > 44) return false;
+    if constexpr (C::HAS_GLV) {
+        GlvRaw raw; u32 dummy[5];
+        if (!glv_decompose<C>(t, dummy, dummy, dummy, dummy, &raw)) return false;
+        ftab_recode(raw.mg1, 3, raw.n1, ctx->ftab_w, ctx->ftab_nwin, d.e1, d.neg1);
+        ftab_recode(raw.mg2, 3, raw.n2, ctx->ftab_w, ctx->ftab_nwin, d.e2, d.neg2);
+    } else {
+        uint64_t c[4]; S::to_canon(c, t);
+        ftab_recode(c, 4, false, ctx->ftab_w, ctx->ftab_nwin, d.e1, d.neg1);
+    }
+    return true;
+}
+// Builds the tables for G[0..n), H[0..n) of the installed generators.  w = 0: the widest window (<= 8 bits) whose tables fit in
+// `budget_bytes` (0 = 3/4 of the free device memory).
+template <class C> static int ftab_build(bp_ctx* ctx, size_t n, int w, size_t budget_bytes) {
+    hipStream_t st = ctx->stream;
+    if (n == 0 || n > ctx->gens_cap) { g_err = "fold tables: more bases than installed generators"; return BP_E_GENS_LENGTH; }
+    if (!ctx->d_G.owned) { g_err = "fold tables: build them on the ctx that owns the generator tables, then bp_gens_share"; return BP_E_ARG; }
+    ctx->ftab_G.release(); ctx->ftab_H.release(); ctx->ftab_n = 0;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if (!budget_bytes) budget_bytes = free_b / 4 * 3;
+    auto bytes_for = [&](int ww) { const size_t E = (size_t)1 << (ww - 1); return 2 * (size_t)ftab_nwin_for<C>(ww) * E * n * 64 + E * n * (96 + 32) + n * 96; };
+    if (w == 0) { w = 8; while (w > 2 && bytes_for(w) > budget_bytes) w--; }
+    if (w < 2 || w > 8 || bytes_for(w) > free_b) { g_err = "fold tables: not enough device memory"; return BP_E_ARG; }
+    const size_t E = (size_t)1 << (w - 1);
+    const int nwin = ftab_nwin_for<C>(w);
+    const size_t per_vec = (size_t)nwin * E * n * 64;
+    BPCHK(ctx->ftab_G.ensure(per_vec)); BPCHK(ctx->ftab_H.ensure(per_vec));
+    DevBuf tmp, pref, state;
+    BPCHK(tmp.ensure(E * n * 96)); BPCHK(pref.ensure(E * n * 32)); BPCHK(state.ensure(n * 96));
+    const u32 gb = (u32)((n + 255) / 256);
+    for (int v = 0; v < 2; v++) {
+        const u32* gens = v ? ctx->d_H.as<u32>() : ctx->d_G.as<u32>();
+        u32* T = v ? ctx->ftab_H.as<u32>() : ctx->ftab_G.as<u32>();
+        for (int j = 0; j < nwin; j++) {
+            hipLaunchKernelGGL(k_ftab_window<C>, dim3(gb), dim3(256), 0, st, gens, state.as<u32>(), tmp.as<u32>(), (u32)n, (u32)E, j == 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_ftab_normalize<C>, dim3(gb), dim3(256), 0, st, tmp.as<u32>(), pref.as<u32>(), T + (size_t)j * E * n * 16, (u32)n, (u32)E);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    tmp.release(); pref.release(); state.release();
+    ctx->ftab_n = n; ctx->ftab_w = w; ctx->ftab_nwin = nwin;
+    return BP_OK;
+}
+// the first-round uniform fold through the tables; false when they do not apply (then the ladder kernels run)
+template <class C> static int launch_tab_fold(bp_ctx* ctx, const IpaState& s, u32* d_G, u32* d_H, size_t n, const F4& tG, const F4& tH, bool& done) {
+    done = false;
+    static const bool off = getenv("ARKBP_FOLD_NOTAB") != nullptr;   // A/B switch
+    if (off || !ctx->ftab_n || !s.gens_stride || n < 64) return BP_OK;
+    if ((size_t)s.gens_first + (n - 1) * (size_t)s.gens_stride >= ctx->ftab_n) return BP_OK;   // left half reaches past the tabled bases
+    FtabDigits dG, dH;
+    if (!ftab_digits<C>(ctx, tG, dG) || !ftab_digits<C>(ctx, tH, dH)) return BP_OK;
+    const u32 lanes = (u32)(2 * n);
+    FoldFinish ff;
+    BPCHK(fold_finish_plan(ctx, lanes, ff));
+    hipLaunchKernelGGL(k_ipa_fold_tab<C>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, ctx->ftab_G.as<u32>(), ctx->ftab_H.as<u32>(), (u32)ctx->ftab_n,
+                       1u << (ctx->ftab_w - 1), d_G, d_H, (u32)n, dG, dH, 3, s.gens_first, s.gens_stride, ff.jac, s.d_G_in, s.d_H_in);
+    fold_finish_launch<C>(ctx->stream, ff, d_G, d_H, n, 3, lanes);
+    done = true;
     return BP_OK;
 }
 
@@ -632,10 +751,12 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
     }
     BaseSegs sg; memset(&sg, 0, sizeof sg);
     sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n; sg.start[2] = (u32)(2 * n); sg.start[3] = (u32)(2 * n + 1);
-    sg.ptr[0] = s.d_G + n * 16; sg.ptr[1] = s.d_H; sg.ptr[2] = s.d_Q;
+    const u32* Gb = s.d_G_in ? s.d_G_in : s.d_G;
+    const u32* Hb = s.d_H_in ? s.d_H_in : s.d_H;
+    sg.ptr[0] = Gb + n * 16; sg.ptr[1] = Hb; sg.ptr[2] = s.d_Q;
     J4 Lj, Rj;
     BPCHK(msm_run<C>(ctx, sg, sL, 2 * n + 1, 0, Lj, 0, -1, s.msm_mode));
-    sg.ptr[0] = s.d_G; sg.ptr[1] = s.d_H + n * 16;
+    sg.ptr[0] = Gb; sg.ptr[1] = Hb + n * 16;
     BPCHK(msm_run<C>(ctx, sg, sR, 2 * n + 1, 0, Rj, 0, -1, s.msm_mode));
     A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
     memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
@@ -654,6 +775,15 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
     const bool first = s.first;
     F4 u; memcpy(u.v, uw, 32);
     F4 ui = S::inv(u);
+    // the ladder kernels fold in place: they need the round-1 inputs in the working vectors (the table fold reads them from the
+    // resident generator tables and needs no copy)
+    auto working_copy = [&]() -> int {
+        if (!s.d_G_in) return BP_OK;
+        HIPCHK(hipMemcpyAsync(s.d_G, s.d_G_in, 2 * n * 64, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(s.d_H, s.d_H_in, 2 * n * 64, hipMemcpyDeviceToDevice, st));
+        s.d_G_in = s.d_H_in = nullptr;
+        return BP_OK;
+    };
     if (s.frozen) {
         ScopedK tk(ctx, BP_K_IPA_FOLD);
         hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
@@ -673,13 +803,16 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
             const int k = ipa_lg2(n);
             const F4 s2 = S::mul(u, s.gf_halves[1]);
             const F4 ginv = S::inv(s.gf_halves[1]);
-            BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, S::mul(S::mul(ui, s.gf_halves[0]), S::inv(s2)),
-                                         S::mul(S::mul(S::sqr(u), S::mul(s.gf_halves[0], ginv)), s.rho_pw[k]), 3));
+            const F4 tG1 = S::mul(S::mul(ui, s.gf_halves[0]), S::inv(s2)), tH1 = S::mul(S::mul(S::sqr(u), S::mul(s.gf_halves[0], ginv)), s.rho_pw[k]);
+            bool tab_done = false;
+            BPCHK(launch_tab_fold<C>(ctx, s, d_G, d_H, n, tG1, tH1, tab_done));   // the bases are the generator tables themselves: fixed-base look-ups
+            if (!tab_done) { BPCHK(working_copy()); BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, tG1, tH1, 3)); }
             s.gamma_G = S::mul(s.gamma_G, s2);
             s.gamma_H = S::mul(S::mul(ui, s.gf_halves[1]), s.rho_pw[32 + k]);
             if (s.have_k0) s.gamma_H = S::mul(s.gamma_H, s.geo_k0);
             s.pending = true; s.h_geo = true;
         } else if (gf_ok) {
+            BPCHK(working_copy());
             // G: u^-1*gL*G_L + u*gR*G_R = (u*gR) * (G_R + t*G_L), t = u^-1*gL / (u*gR): uniform, one NAF ladder; H: per-lane factors
             const F4 s2 = S::mul(u, s.gf_halves[1]);
             const F4 tG = S::mul(S::mul(ui, s.gf_halves[0]), S::inv(s2));
@@ -691,6 +824,7 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
             s.gamma_G = S::mul(s.gamma_G, s2);
             s.pending = true;
         } else if (first) {
+            BPCHK(working_copy());
             FoldFinish ff;
             BPCHK(fold_finish_plan(ctx, 2 * n, ff));
             hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, s.d_Gf, s.d_Hf, 1, (u32)n, words_of<S>(u),
@@ -708,6 +842,7 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
     }
     HIPCHK(hipGetLastError());
     s.first = false;
+    s.d_G_in = s.d_H_in = nullptr;
     s.round++;
     s.n = n;
     s.lr_done = false;
@@ -745,9 +880,14 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                           const F4* gf_halves = nullptr /* optional hint: G_factors == gf_halves[0] on [0,n/2) and gf_halves[1] on [n/2,n) */,
                           const F4* rho_pw = nullptr /* optional hint (with gf_halves): H_factors[i] = rho^i * G_factors[i];
                                                         rho_pw[k] = rho^-(2^k), rho_pw[32+k] = rho^(2^k), k < 32 */,
-                          const u32* d_rho_pow = nullptr /* device table of rho^(2^k), resident words */) {
+                          const u32* d_rho_pow = nullptr /* device table of rho^(2^k), resident words */,
+                          bool gens_are_tables = false /* d_G, d_H stand for the ctx's generator tables G[0..n), H[0..n) */,
+                          bool gens_in_place = false /* ... and were NOT copied: round 1 reads ctx->d_G / d_H, d_G / d_H receive its output */) {
     IpaState s;
     BPCHK(ipa_begin_dev<C>(ctx, s, d_Q, d_Gf, d_Hf, d_G, d_H, d_a, d_b, n, gf_halves, rho_pw, d_rho_pow, true));
+    if (gens_are_tables) { s.gens_first = 0; s.gens_stride = 1; }
+    if (gens_in_place) { s.d_G_in = ctx->d_G.as<u32>(); s.d_H_in = ctx->d_H.as<u32>(); }
+    if (n == 1) s.d_G_in = s.d_H_in = nullptr;
     while (s.n != 1) {
         uint64_t Lw[8], Rw[8], uw[4];
         BPCHK(ipa_round_lr<C>(ctx, s, Lw, Rw));
@@ -806,6 +946,7 @@ static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const
     BPCHK(ipa_begin_dev<C>(ctx, s, d_Q, ctx->cyc_Gf.as<u32>(), ctx->cyc_Hf.as<u32>(), ctx->ipa_G.as<u32>(), ctx->ipa_H.as<u32>(), ctx->cyc_a.as<u32>(),
                            ctx->cyc_b.as<u32>(), n_loc, gf_halves, geo ? rho_loc : nullptr, geo ? d_rho_pow + (size_t)w * 8 : nullptr, false));
     s.msm_mode = 2;
+    s.gens_first = (u32)r; s.gens_stride = (u32)W;
     F4 rho_r = S::one(), rho_mr = S::one();   // rho^rank, rho^-rank
     if (geo) for (int k = 0; k < w; k++) if ((r >> k) & 1) { rho_r = S::mul(rho_r, rho_pw[32 + k]); rho_mr = S::mul(rho_mr, rho_pw[k]); }
     s.geo_k0 = rho_r; s.have_k0 = geo;
@@ -1341,7 +1482,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
-                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->cyc_a, &c->cyc_b, &c->cyc_Gf, &c->cyc_Hf, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab};
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->cyc_a, &c->cyc_b, &c->cyc_Gf, &c->cyc_Hf, &c->ftab_G, &c->ftab_H, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab};
     c->templates.clear();
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -1521,6 +1662,16 @@ int bp_gens_upload(bp_ctx* c, const uint64_t* G_xy, const uint64_t* H_xy, size_t
     if (!c || !G_xy || !H_xy || !cap) return BP_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     return c->curve == 0 ? gens_install<Secq>(c, G_xy, H_xy, cap) : gens_install<Zorro>(c, G_xy, H_xy, cap);
+}
+int bp_gens_fold_tables(bp_ctx* c, size_t count, int window_bits, size_t budget_bytes, int* window_bits_out, size_t* bytes_out) {
+    if (!c || window_bits < 0 || window_bits == 1 || window_bits > 8) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (count == 0) { if (c->ftab_G.owned) { c->ftab_G.release(); c->ftab_H.release(); } c->ftab_n = 0; return BP_OK; }
+    const int rc = c->curve == 0 ? ftab_build<Secq>(c, count, window_bits, budget_bytes) : ftab_build<Zorro>(c, count, window_bits, budget_bytes);
+    if (rc) return rc;
+    if (window_bits_out) *window_bits_out = c->ftab_w;
+    if (bytes_out) *bytes_out = 2 * (size_t)c->ftab_nwin * ((size_t)1 << (c->ftab_w - 1)) * c->ftab_n * 64;
+    return BP_OK;
 }
 int bp_gens_download(bp_ctx* c, uint64_t* G_xy, uint64_t* H_xy, size_t n) {
     if (!c || !G_xy || !H_xy || n > c->gens_cap) return BP_E_ARG;
@@ -1824,6 +1975,10 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src) {
     DevBuf* sr[] = {&src->d_G, &src->d_H, &src->d_pc};
     for (int i = 0; i < 3; i++) { d[i]->release(); d[i]->p = sr[i]->p; d[i]->cap = sr[i]->cap; d[i]->owned = false; }
     dst->gens_cap = src->gens_cap; dst->pc_B = src->pc_B; dst->pc_Bb = src->pc_Bb;
+    DevBuf* dt[] = {&dst->ftab_G, &dst->ftab_H};
+    DevBuf* stb[] = {&src->ftab_G, &src->ftab_H};
+    for (int i = 0; i < 2; i++) { dt[i]->release(); dt[i]->p = stb[i]->p; dt[i]->cap = stb[i]->cap; dt[i]->owned = false; }
+    dst->ftab_n = src->ftab_n; dst->ftab_w = src->ftab_w; dst->ftab_nwin = src->ftab_nwin;
     return BP_OK;
 }
 

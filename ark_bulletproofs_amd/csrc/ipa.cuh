@@ -410,4 +410,108 @@ k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH
     fold_emit<C>(V, i, t, acc, jac_ws);
 }
 
+// ---- fixed-base tables for the FIRST fold round ------------------------------------------------------------------------------
+// Round 1 folds the generator tables themselves: Ghat'[i] = G[n+i] + t*G[i] with ONE multiplier t for all i (uniform rounds, see
+// k_ipa_fold_uniform) and bases that are the same for every proof — BulletproofGens is fixed, the reference clones it per proof
+// (src/r1cs/prover.rs:796-797).  So t*G[i] can be a fixed-base multiplication: the table holds e * 2^(w*j) * G[i] for every
+// window j and digit magnitude e in [1, 2^(w-1)], affine, laid out [j][e-1][i].  Because t is wave-uniform, every lane of a wave
+// needs the SAME (j, e) row: a window's look-up is one coalesced 64 B x 64 read, and the lane does one mixed add per non-zero
+// digit and NO doublings — 34 mixed adds (w = 8, GLV halves) instead of 130 doublings + ~88 mixed adds.  Half of all fold work of a
+// proof is in round 1.  The tables are large (2^19 bases, w = 8: 73 GB per vector) and live in HBM for the life of the ctx — the
+// MI355X has 288 GB of it and this path touches HBM at < 1 % of its bandwidth otherwise.
+struct FtabDigits {
+    unsigned short e1[44], e2[44];   // per window: |digit| of t1 (and of t2, the GLV half that goes with phi(P)); 0 = skip
+    unsigned long long neg1, neg2;   // bit j: the digit of window j is negative
+    u32 nwin;
+};
+// one window of the table for bases [0, n): state[i] = 2^(w*j) * P_i on entry (Jacobian; first != 0: taken from the generator table),
+// 2^(w*(j+1)) * P_i on exit; tmp[(e-1)*n + i] = e * state_in[i] (Jacobian) for e = 1..E, E = 2^(w-1)
+template <class C> __global__ void __launch_bounds__(256)
+k_ftab_window(const u32* __restrict__ gens, u32* __restrict__ state, u32* __restrict__ tmp, u32 n, u32 E, int first) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Jac B;
+    if (first) { const Aff p = load_aff_dev(gens + (size_t)i * 16); B = jac_madd<C>(jac_inf<C>(), p); }
+    else B = load_jac_ws(state + (size_t)i * 24);
+    Jac acc = B;
+    store_jac_ws<C>(tmp + (size_t)i * 24, acc);
+#pragma unroll 1
+    for (u32 e = 2; e <= E; e++) {
+        acc = jac_add<C>(acc, B);
+        store_jac_ws<C>(tmp + ((size_t)(e - 1) * n + i) * 24, acc);
+    }
+    store_jac_ws<C>(state + (size_t)i * 24, jac_dbl<C>(acc));   // 2 * E * B = 2^w * B
+}
+// tmp (E x n Jacobian) -> out (E x n affine, resident layout) with one inversion per lane (Montgomery's trick along e)
+template <class C> __global__ void __launch_bounds__(256)
+k_ftab_normalize(const u32* __restrict__ tmp, u32* __restrict__ pref, u32* __restrict__ out, u32 n, u32 E) {
+    typedef typename C::Fq F;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe acc = fe_one<F>();
+#pragma unroll 1
+    for (u32 e = 0; e < E; e++) {
+        u32 w[8];
+        load_words8(w, tmp + ((size_t)e * n + i) * 24 + 16);
+        const Fe z = fe_unpack(w);
+        if (!fe_is_zero_exact(z)) acc = fe_mul<F>(acc, z);
+        fe_pack(w, fe_canon<F>(acc));
+        store_words8(pref + ((size_t)e * n + i) * 8, w);
+    }
+    Fe inv = fe_inv<F>(acc);
+#pragma unroll 1
+    for (int e = (int)E - 1; e >= 0; e--) {
+        const Jac P = load_jac_ws(tmp + ((size_t)e * n + i) * 24);
+        Aff o;
+        if (jac_is_inf(P)) { o.x = fe_zero<F>(); o.y = fe_zero<F>(); }
+        else {
+            Fe prev = fe_one<F>();
+            if (e > 0) { u32 w[8]; load_words8(w, pref + ((size_t)(e - 1) * n + i) * 8); prev = fe_unpack(w); }
+            const Fe zinv = fe_mul<F>(inv, prev);
+            inv = fe_mul<F>(inv, P.Z);
+            o = jac_to_aff_with_zinv<C>(P, zinv);
+        }
+        u32 w[16];
+        aff_store_dev(w, o);
+        store_words8(out + ((size_t)e * n + i) * 16, w);
+        store_words8(out + ((size_t)e * n + i) * 16 + 8, w + 8);
+    }
+}
+// the first-round uniform fold from the tables: lane t -> V[i] = V[n+i] + t_V * Base(g_first + i*g_stride), V = G (lanes [0, n)) or H.
+// G, H: the working vectors (their upper halves are read, their lower halves written — or the Jacobian workspace, see fold_emit).
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_fold_tab(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_tab, u32 E, u32* __restrict__ G, u32* __restrict__ H, u32 n, FtabDigits dG,
+               FtabDigits dH, int which, u32 g_first, u32 g_stride, u32* __restrict__ jac_ws,
+               const u32* __restrict__ Gin /* nullable: read the upper halves from here (the resident generator tables) instead of G / H */,
+               const u32* __restrict__ Hin) {
+    typedef typename C::Fq F;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (which == 3 ? 2 * n : n)) return;
+    const bool isH = which == 2 || (which == 3 && t >= n);   // waves are homogeneous for n >= 64
+    const u32 i = (which == 3 && isH) ? t - n : t;
+    u32* V = isH ? H : G;
+    const u32* T = isH ? TH : TG;
+    const u32 gi = g_first + i * g_stride;
+    Jac acc = jac_inf<C>();
+    const u32 nwin = isH ? dH.nwin : dG.nwin;
+#pragma unroll 1
+    for (u32 j = 0; j < nwin; j++) {
+        const u32 e1 = isH ? dH.e1[j] : dG.e1[j], e2 = isH ? dH.e2[j] : dG.e2[j];
+        if (e1) {
+            const Aff P = load_aff_dev(T + (((size_t)j * E + (e1 - 1)) * n_tab + gi) * 16);
+            acc = jac_madd<C>(acc, aff_cneg_lazy<C>(P, (((isH ? dH.neg1 : dG.neg1) >> j) & 1ull) != 0));
+        }
+        if constexpr (C::HAS_GLV) {
+            if (e2) {
+                Aff Q = load_aff_dev(T + (((size_t)j * E + (e2 - 1)) * n_tab + gi) * 16);
+                if (!aff_is_inf(Q)) Q.x = fe_canon<F>(fe_mul<F>(Q.x, fe_const<F, C::BETA29>()));   // phi(x, y) = (beta * x, y)
+                acc = jac_madd<C>(acc, aff_cneg_lazy<C>(Q, (((isH ? dH.neg2 : dG.neg2) >> j) & 1ull) != 0));
+            }
+        } else { (void)e2; }
+    }
+    const u32* Vin = isH ? (Hin ? Hin : H) : (Gin ? Gin : G);
+    acc = jac_madd<C>(acc, load_aff_dev(Vin + (size_t)(n + i) * 16));
+    fold_emit<C>(V, i, t, acc, jac_ws);
+}
+
 }  // namespace arkbp

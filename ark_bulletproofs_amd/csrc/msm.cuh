@@ -47,6 +47,20 @@ __device__ __forceinline__ const u32* seg_base_ptr(const BaseSegs& s, u32 idx) {
     return s.ptr[k] + (size_t)(idx - s.start[k]) * 16;
 }
 
+// The scalar vector of an MSM, likewise: up to 4 device-resident runs (e.g. blinding || a_L || a_R of a commitment,
+// src/r1cs/prover.rs:516-531) read in place instead of being concatenated first.
+struct ScalSegs {
+    const u32* ptr[MSM_MAXSEG];   // 8 words per scalar
+    u32 start[MSM_MAXSEG + 1];
+    int nseg;
+};
+__device__ __forceinline__ const u32* seg_scalar_ptr(const ScalSegs& s, u32 idx) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MSM_MAXSEG; j++) k += (j < s.nseg && idx >= s.start[j]) ? 1 : 0;
+    return s.ptr[k] + (size_t)(idx - s.start[k]) * 8;
+}
+
 struct MsmPlan {
     int c, W, NB;        // window bits, windows, buckets per window (2^(c-1))
     u32 B;               // W * NB
@@ -138,7 +152,7 @@ __device__ __forceinline__ u32 wave_count(u32* __restrict__ ctr, u32 key, bool v
 
 // 1. digits + histogram.  scalars_mont: 0 canonical integers, 1 ark Montgomery words, 2 resident layout.
 template <class C> __global__ void __launch_bounds__(256)
-k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont, SlotPlan sp,
+k_msm_digits(ScalSegs scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont, SlotPlan sp,
              u32* __restrict__ slots, u32* __restrict__ overflow) {
     typedef typename C::Fr Fr;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,7 +161,7 @@ k_msm_digits(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __re
 #pragma unroll
     for (int j = 0; j < 8; j++) k[j] = 0;
     if (live) {
-        load_words8(k, scalars + (size_t)i * 8);
+        load_words8(k, seg_scalar_ptr(scalars, i));
         if (scalars_mont == 1) {          // ark Montgomery words (R = 2^256)
             Fe s = fe_load_ark<Fr>(k);
             fe_store_canon<Fr>(k, s);
@@ -186,7 +200,7 @@ struct BinPlan {
 };
 // entry in a bin region: (term << (LB+1)) | (fine bucket << 1) | sign
 template <class C> __global__ void __launch_bounds__(256)
-k_msm_bin_partition(const u32* __restrict__ scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont, BinPlan bp,
+k_msm_bin_partition(ScalSegs scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont, BinPlan bp,
                     SlotPlan sp, u32* __restrict__ bin_cur, u32* __restrict__ ent, u32* __restrict__ overflow, int wa, int we, int first) {
     typedef typename C::Fr Fr;
     extern __shared__ u32 lds_cnt[];   // (we - wa) * NBIN bin counters, then top_nb bucket counters of the slot window
@@ -203,7 +217,7 @@ k_msm_bin_partition(const u32* __restrict__ scalars, u32* __restrict__ canon, u3
         const u32 i = tile0 + t * 256u + threadIdx.x;
         if (i >= pl.n) break;
         u32 k[8];
-        load_words8(k, scalars + (size_t)i * 8);
+        load_words8(k, seg_scalar_ptr(scalars, i));
         if (scalars_mont == 1) { Fe s = fe_load_ark<Fr>(k); fe_store_canon<Fr>(k, s); }
         else if (scalars_mont == 2) { Fe s = fe_unpack(k); fe_store_canon<Fr>(k, s); }
         if (first) store_words8(canon + (size_t)i * 8, k);
@@ -456,6 +470,51 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
         }
     }
     store_jac_ws<C>(out + (size_t)j * 24, acc);
+}
+
+// 4b. A/B arm of the accumulate study — the shape BASELINE.json's north_star prescribes: ONE WAVEFRONT PER BUCKET.  Lane l of the
+// wave gathers entries l, l + 64, ... of its bucket (the entry words are one coalesced read, the bases are 64 B gathers), sums
+// them with mixed adds, and the 64 partial sums meet in a 6-level tree through LDS.  The bucket's single sum lands where the last
+// tree level of the chunked path would put it (off_last[b]), so no reduce level follows.  Selected by ARKBP_MSM_ACCUM=wave;
+// measured against the lane-per-16-entry-chunk kernel in profiles/r02_accum_ab_*.  Its weakness is arithmetic, not memory: with
+// c = 14-15 a bucket holds ~64-128 entries, i.e. 1-2 mixed adds per lane, and then the tree runs 6 full-price Jacobian additions
+// on 32, 16, 8, 4, 2, 1 active lanes — ~1.5 modular-product slots per entry against 0.17 for the chunked kernel.
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_accum_wave(BaseSegs segs, const u32* __restrict__ entries, const u32* __restrict__ off0, const u32* __restrict__ off_last, u32* __restrict__ out, u32 B,
+                 int slotted, SlotPlan sp, u32 NB, const u32* __restrict__ boff) {
+    __shared__ u32 sh[4][64 * 27];
+    const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 b = blockIdx.x * 4 + wv;
+    if (b >= B) return;                                  // (whole waves leave together)
+    const u32 cnt = off0[b + 1] - off0[b];
+    if (!cnt) return;
+    u32 beg;
+    if (slotted == 2) beg = boff[b];
+    else if (slotted) { const u32 w = b / NB, v = b - w * NB; beg = sp.base[w] + v * sp.cap[w]; }
+    else beg = off0[b];
+    Jac acc = jac_inf<C>();
+    for (u32 e = lane; e < cnt; e += 64) {
+        const u32 ent = entries[beg + e];
+        acc = jac_madd<C>(acc, aff_cneg_lazy<C>(load_aff_dev(seg_base_ptr(segs, ent >> 1)), ent & 1));
+    }
+    u32* s = sh[wv];
+    for (u32 stride = 32; stride >= 1; stride >>= 1) {
+        if (lane >= stride && lane < 2 * stride) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) { s[i * 64 + lane] = acc.X.l[i]; s[(9 + i) * 64 + lane] = acc.Y.l[i]; s[(18 + i) * 64 + lane] = acc.Z.l[i]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (lane < stride) {
+            Jac o;
+#pragma unroll
+            for (int i = 0; i < 9; i++) { o.X.l[i] = s[i * 64 + lane + stride]; o.Y.l[i] = s[(9 + i) * 64 + lane + stride]; o.Z.l[i] = s[(18 + i) * 64 + lane + stride]; }
+            acc = jac_add<C>(acc, o);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    if (lane == 0) store_jac_ws<C>(out + (size_t)off_last[b] * 24, acc);
 }
 
 // 5. level k >= 2: lane j sums chunk j of level k-1 partials

@@ -230,7 +230,7 @@ class ProvePipeline:
     """The prove workload's three stages, all inside the timed region:
 
       build   (host pool)  Prover::new + commit + gadget for statement k (the reference's benchmark builds these inside its
-                           timed closure too, benches/r1cs_secq256k1.rs:172-184).  At most `window` statements are alive at once
+                           timed closure too, benches/r1cs_secq256k1.rs:172-184).  At most `--window` statements are alive at once
                            (built, not yet proved): a 2^20 statement holds ~0.3 GB of witness + constraints.
       stage 1 (host pool)  the head of prove(): the TranscriptRng chain — 8 sequential Keccak-f per multiplier, the reference's
                            design — for groups of 8 consecutive statements in AVX-512 lockstep.
@@ -243,7 +243,7 @@ class ProvePipeline:
 
     def run(self, tag, count, out):
         E, args, engs = self.E, self.args, self.engs
-        window = max(16, 2 * args.batch)
+        window = max(16, args.window)
         built = [None] * count
         built_ev = [threading.Event() for _ in range(count)]
         slots = threading.Semaphore(window)
@@ -251,6 +251,12 @@ class ProvePipeline:
         lock = threading.Lock()
         nxt_build, nxt_pre = [0], [0]
         ready = queue.Queue()
+        waits = self.waits = {"build_wait_slot": 0.0, "build_busy": 0.0, "rng_wait_build": 0.0, "rng_busy": 0.0, "gpu_wait_ready": 0.0, "gpu_busy": 0.0}
+        wlock = threading.Lock()
+
+        def acct(key, dt):
+            with wlock:
+                waits[key] += dt
 
         def wait(ev_or_sem, is_sem=False):
             while not stop.is_set():
@@ -275,10 +281,14 @@ class ProvePipeline:
                     nxt_build[0] += 1
                 if k >= count:
                     return
+                t0 = time.perf_counter()
                 if not wait(slots, True):
                     return
+                t1 = time.perf_counter()
                 built[k] = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [self.N, 0], statement_seed(tag, k))
                 built_ev[k].set()
+                acct("build_wait_slot", t1 - t0)
+                acct("build_busy", time.perf_counter() - t1)
 
         @guarded
         def stage1():
@@ -289,28 +299,37 @@ class ProvePipeline:
                 if i >= count:
                     return
                 grp = list(range(i, min(i + 8, count)))
+                t0 = time.perf_counter()
                 for g in grp:
                     if not wait(built_ev[g]):
                         return
+                t1 = time.perf_counter()
                 E.precompute_batch([built[g] for g in grp])   # 8 chains in lockstep in AVX-512 lanes (Keccak-f x8)
                 for g in grp:
                     ready.put(g)
+                acct("rng_wait_build", t1 - t0)
+                acct("rng_busy", time.perf_counter() - t1)
 
         @guarded
         def stage2(k):
             while True:
+                t0 = time.perf_counter()
                 try:
                     i = ready.get(timeout=0.2)
                 except queue.Empty:
+                    acct("gpu_wait_ready", time.perf_counter() - t0)
                     if stop.is_set():
                         return
                     continue
                 if i is None:
                     return
+                t1 = time.perf_counter()
                 out[i] = built[i].prove(engs[k])
                 built[i].free()   # a consumed statement (witness + constraints, ~0.3 GB at 2^20) is released at once
                 built[i] = None
                 slots.release()
+                acct("gpu_wait_ready", t1 - t0)
+                acct("gpu_busy", time.perf_counter() - t1)
 
         def producers():
             run_threads([(build, ())] * args.build_threads + [(stage1, ())] * args.host_threads)
@@ -345,6 +364,12 @@ def run_prove(args, rank, world, local):
     t0 = time.perf_counter()
     engs[0].gens_derive(N)
     t_gens = time.perf_counter() - t0
+    tab_info = None
+    if args.fold_tables:
+        # fixed-base tables of the generators for the first fold round (one-time setup like the derivation above; HBM-resident)
+        t0 = time.perf_counter()
+        wbits, nbytes = engs[0].gens_fold_tables(N // 2, window_bits=args.fold_table_bits)
+        tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0}
     for e in engs[1:]:
         e.share_gens_from(engs[0])
     if window_sharded:
@@ -367,6 +392,8 @@ def run_prove(args, rank, world, local):
     pipe.run(0, nproofs, flat)                   # K steps x `batch` proofs, statement construction included
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
+    # thread-seconds of every stage of the timed pipeline (busy / waiting for its input), as fractions of (threads x wall)
+    pipe_util = {k: v / dt for k, v in pipe.waits.items()}
     stages = np.zeros(8)
     for (_, tm) in flat:
         stages += np.array(tm)
@@ -391,7 +418,7 @@ def run_prove(args, rank, world, local):
                                % (args.logn, CURVES[args.curve], args.batch, P, args.host_threads, args.build_threads),
                    "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "build_threads": args.build_threads,
                    "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
-                   "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens,
+                   "pipeline_thread_seconds_per_wall_second": pipe_util, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
     if fold_n:
@@ -561,6 +588,10 @@ def main():
     ap.add_argument("--host-threads", type=int, default=3, help="host threads running the TranscriptRng head of prove()")
     ap.add_argument("--build-threads", type=int, default=3, help="host threads constructing statements (Prover::new + commit + gadget)")
     ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
+    ap.add_argument("--window", type=int, default=64, help="statements alive at once in the prove pipeline (built, waiting for or in the TranscriptRng stage, "
+                    "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s")
+    ap.add_argument("--fold-tables", type=int, default=1, help="prove workload: fixed-base tables of the generators for the first fold round (0 = off)")
+    ap.add_argument("--fold-table-bits", type=int, default=0, help="window width of those tables (0 = the widest that fits in 3/4 of the free HBM)")
     ap.add_argument("--terms", type=int, default=1 << 16)
     ap.add_argument("--shard", default="terms", choices=["terms", "windows"],
                     help="multi-GPU partition: msm workload: terms | Pippenger windows; prove workload: replicas (default) | windows = every rank proves the same statements with window-sharded MSMs")

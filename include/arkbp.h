@@ -145,6 +145,14 @@ int bp_ipa_verify(bp_ctx* ctx, size_t n, const uint64_t* G_factors, const uint64
 int bp_gens_derive(bp_ctx* ctx, size_t gens_capacity);
 int bp_gens_upload(bp_ctx* ctx, const uint64_t* G_xy, const uint64_t* H_xy, size_t gens_capacity);
 int bp_gens_download(bp_ctx* ctx, uint64_t* G_xy, uint64_t* H_xy, size_t n);
+/* Optional: fixed-base tables of G[0..count), H[0..count) for the FIRST fold round of the prover's inner-product argument
+ * (src/inner_product_proof.rs:139-156: there the bases are the generator tables themselves, the same for every proof, and the
+ * multiplier is one scalar for all elements) — e * 2^(w*j) * G[i] for all windows j and digits e, so that the round becomes
+ * ~34 look-ups + mixed adds per point (w = 8) instead of a 130-step double-and-add ladder.  count = the left half of the largest
+ * proof: N/2.  window_bits 2..8, or 0 = the widest whose tables fit in budget_bytes (0 = 3/4 of the free device memory); the
+ * choice and the table size come back in *window_bits_out / *bytes_out (2^19 bases, w = 8: 146 GB for both vectors on secq256k1).
+ * Built on the ctx that owns the generators; bp_gens_share hands them on.  count = 0 frees them.  Results never depend on it. */
+int bp_gens_fold_tables(bp_ctx* ctx, size_t count, int window_bits, size_t budget_bytes, int* window_bits_out, size_t* bytes_out);
 /* PedersenGens::default() -> (B, B_blinding); host only */
 int bp_pedersen_gens(int curve, uint64_t B_xy[8], uint64_t B_blinding_xy[8]);
 /* GeneratorsChain for label 'G'|'H' || LE32(party) (src/generators.rs:71-121), first `count` points; host only */

@@ -247,3 +247,33 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
             assert proof == ref.proof and rc == 0
         assert big_gathers[r] == len(cases), "the index-cyclic IPA path was not taken"
     single.close()
+
+
+@pytest.mark.parametrize("w", [0, 3, 8])
+def test_prove_with_first_round_fold_tables(oracle, w):
+    """bp_gens_fold_tables: the first fold round through fixed-base tables of the generators (window widths 3, 8 and the
+    automatic choice) must leave the proofs byte-identical to the oracle's — square chains (constant G factors, geometric H
+    factors), shuffles (all multipliers randomized: G factors all u) and multi-range circuits, 128 to 1024 multipliers, with the
+    shared-inversion epilogue both off and forced on; a statement whose left half is larger than the tables falls back to the ladder"""
+    import ark_bulletproofs_amd as A
+
+    for cv in (0, 1):
+        e = A.Engine(curve=cv)
+        e.gens_derive(1024)
+        wb, nbytes = e.gens_fold_tables(256, window_bits=w)
+        assert 2 <= wb <= 8 and nbytes > 0 and (w == 0 or wb == w)
+        for batch_min in (65536, 1):
+            e.set_tuning(0, batch_min)      # BP_TUNE_FOLD_BATCH_MIN: in-lane inversions / the shared-inversion epilogue
+            for sc, prm in [(3, [100, 0]), (3, [500, 0]), (0, [65]), (0, [200]), (4, [16, 16, 0]), (3, [1000, 0])]:
+                ref = oracle.r1cs_prove(cv, sc, prm, SEED, 1024, m_cap=512)
+                got = e.prove_scenario(sc, prm, SEED, m_cap=512)
+                assert got.proof == ref.proof, (cv, w, sc, prm)
+        # the tables go along with bp_gens_share
+        e2 = A.Engine(curve=cv)
+        e2.share_gens_from(e)
+        ref = oracle.r1cs_prove(cv, 3, [300, 0], SEED, 1024, m_cap=8)
+        assert e2.prove_scenario(3, [300, 0], SEED, m_cap=8).proof == ref.proof
+        e2.close()
+        e.gens_fold_tables(0)
+        assert e.prove_scenario(3, [300, 0], SEED, m_cap=8).proof == ref.proof
+        e.close()

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "ec.cuh"
+#include "msm.cuh"
 using namespace arkbp;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -89,6 +89,54 @@ template <class C> __global__ void k_dbl(const u32* a, u32* out, int iters) {
     fe_pack(out + 8 * i, fe_canon<typename C::Fq>(acc.X));
 }
 
+// ---- A/B arm (a) of the accumulate study: batched-affine addition (Montgomery's trick) ----------------------------------------
+// pts: 2*npairs affine points (resident layout, 64 B each); out[i] = pts[2i] + pts[2i+1] (affine); pref: npairs x 8 words scratch.
+// Lane t owns the pairs t, t + T, t + 2T, ... (T = lanes of the grid: coalesced at every step), M of them per inversion:
+// pass 1 multiplies the denominators x2 - x1 into a running product (stored per pair), one inversion, pass 2 walks back and
+// forms lambda, x3, y3.  6 modular products per addition + one inversion per M, against 11 for jac_madd — but every addition
+// moves 2 x 64 B in, 32 + 32 B of prefix scratch, 64 B out, and reads the x coordinates twice.
+template <class C> __global__ void __launch_bounds__(256) k_baff(const u32* __restrict__ pts, u32* __restrict__ pref, u32* __restrict__ out, u32 npairs, u32 M) {
+    typedef typename C::Fq F;
+    const u32 T = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 >= npairs) return;
+    Fe acc = fe_one<F>();
+    u32 cnt = 0;
+    for (u32 p = t0; cnt < M && p < npairs; cnt++, p += T) {
+        u32 w[8];
+        load_words8(w, pts + (size_t)(2 * p) * 16); const Fe x1 = fe_unpack(w);
+        load_words8(w, pts + (size_t)(2 * p + 1) * 16); const Fe x2 = fe_unpack(w);
+        acc = fe_mul<F>(acc, fe_wred<F>(fe_sub<F, 2>(x2, x1)));
+        fe_pack(w, fe_canon<F>(acc));
+        store_words8(pref + (size_t)p * 8, w);
+    }
+    Fe inv = fe_inv<F>(acc);
+    for (int j = (int)cnt - 1; j >= 0; j--) {
+        const u32 p = t0 + (u32)j * T;
+        const Aff P = load_aff_dev(pts + (size_t)(2 * p) * 16), Q = load_aff_dev(pts + (size_t)(2 * p + 1) * 16);
+        Fe prev = fe_one<F>();
+        if (j > 0) { u32 w[8]; load_words8(w, pref + (size_t)(p - T) * 8); prev = fe_unpack(w); }
+        const Fe d = fe_wred<F>(fe_sub<F, 2>(Q.x, P.x));
+        const Fe dinv = fe_mul<F>(inv, prev);
+        inv = fe_mul<F>(inv, d);
+        const Fe lam = fe_mul<F>(fe_wred<F>(fe_sub<F, 2>(Q.y, P.y)), dinv);
+        const Fe x3 = fe_wred<F>(fe_sub<F, 4>(fe_sqr<F>(lam), fe_norm(fe_add(P.x, Q.x))));
+        const Fe y3 = fe_wred<F>(fe_sub<F, 2>(fe_mul<F>(lam, fe_wred<F>(fe_sub<F, 2>(P.x, x3))), P.y));
+        Aff o; o.x = fe_canon<F>(x3); o.y = fe_canon<F>(y3);
+        u32 w[16];
+        aff_store_dev(w, o);
+        store_words8(out + (size_t)p * 16, w);
+        store_words8(out + (size_t)p * 16 + 8, w + 8);
+    }
+}
+// the same additions as mixed Jacobian adds through memory (what one level of a Jacobian tree costs): out = 96 B Jacobian
+template <class C> __global__ void __launch_bounds__(256) k_madd_mem(const u32* __restrict__ pts, u32* __restrict__ out, u32 npairs) {
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const Aff P = load_aff_dev(pts + (size_t)(2 * p) * 16), Q = load_aff_dev(pts + (size_t)(2 * p + 1) * 16);
+    const Jac r = jac_madd<C>(jac_madd<C>(jac_inf<C>(), P), Q);
+    store_jac_ws<C>(out + (size_t)p * 24, r);
+}
+
 template <class F> double time_kernel(F launch, int reps = 5) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -152,5 +200,21 @@ int main() {
       printf("jac_madd zorro  waves/SIMD=4  %8.3f ms  %8.2f G madd/s\n", s * 1e3, 1.0 * it * b2 * threads / s / 1e9);
       s = time_kernel([&] { k_dbl<Zorro><<<b2, threads>>>(in, outp, it); });
       printf("jac_dbl  zorro  waves/SIMD=4  %8.3f ms  %8.2f G dbl/s\n", s * 1e3, 1.0 * it * b2 * threads / s / 1e9); }
+    // ---- batched-affine additions through memory vs mixed adds (accumulate A/B, arm a) ----
+    {
+        const u32 npairs = 1u << 22;   // 4 M additions: 512 MB of input points
+        u32 *pts, *pref, *outb;
+        CHECK(hipMalloc(&pts, (size_t)npairs * 2 * 64)); CHECK(hipMalloc(&pref, (size_t)npairs * 32)); CHECK(hipMalloc(&outb, (size_t)npairs * 96));
+        // distinct valid-looking field elements are enough for timing (no exceptional cases): x in [1, 2^250)
+        { std::vector<u32> h((size_t)npairs * 2 * 16); u32 x = 777; for (size_t i = 0; i < h.size(); i++) { x = x * 1664525u + 1013904223u; h[i] = (i % 8 == 7) ? (x >> 8) : x; } CHECK(hipMemcpy(pts, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
+        double s = time_kernel([&] { k_madd_mem<Secq><<<npairs / 256, 256>>>(pts, outb, npairs); });
+        printf("madd through memory (2 x 64 B in, 96 B out)        %8.3f ms  %7.2f G adds/s  %6.0f GB/s\n", s * 1e3, npairs / s / 1e9, npairs * 224.0 / s / 1e9);
+        for (u32 M : {8u, 16u, 32u, 64u, 128u, 256u}) {
+            const u32 lanes = npairs / M;
+            s = time_kernel([&] { k_baff<Secq><<<(lanes + 255) / 256, 256>>>(pts, pref, outb, npairs, M); });
+            printf("batched-affine add, M = %3u per inversion (%7u lanes) %8.3f ms  %7.2f G adds/s  %6.0f GB/s\n", M, lanes, s * 1e3, npairs / s / 1e9, npairs * 320.0 / s / 1e9);
+        }
+        CHECK(hipFree(pts)); CHECK(hipFree(pref)); CHECK(hipFree(outb));
+    }
     return 0;
 }
