@@ -85,6 +85,8 @@ struct IpaState {
     u32 gens_first = 0, gens_stride = 0;
     // round 1 may read the generators straight from the ctx's resident tables (no working copy): non-null until the first fold
     const u32 *d_G_in = nullptr, *d_H_in = nullptr;
+    bool have_qw = false;      // Q = qw * B (the R1CS prover's Q, prover.rs:779): lets round 1 run as a fixed-base MSM over the tables
+    F4 qw;
     int msm_mode = -1;
     F4 geo_k0;                  // index-cyclic slices: the geometric H factor of local element j is K * rho^(rank + j*world) = (K * geo_k0) * (rho^world)^j
     bool have_k0 = false;
@@ -117,6 +119,8 @@ struct bp_ctx {
     void* h_vstage[2] = {nullptr, nullptr};   // pinned staging halves of the batch-verify pipeline
     size_t h_vstage_cap[2] = {0, 0};
     hipEvent_t vstage_ev[2] = {nullptr, nullptr};
+    void* h_upload = nullptr;                 // pinned slab for the prover's witness uploads (r1cs_host.inc upload_scalars_pinned)
+    size_t h_upload_cap = 0;
     void* h_dec = nullptr;                    // pinned: x words, points, flags, ok of a batch's compressed points
     size_t h_dec_cap = 0;
     hipStream_t aux_stream = nullptr;         // point decompression runs beside the main stream
@@ -135,6 +139,9 @@ struct bp_ctx {
     void* gather_user = nullptr;
     size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
     DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
+    // fixed-base MSM rows of the generators (bp_gens_msm_tables): row r of a table = 2^(4r) * base, r < FB_ROWS, layout [r][i]
+    DevBuf fb_G, fb_H, fb_pc;
+    size_t fb_cap = 0;       // bases covered per vector
     // fixed-base tables of the generators for the first fold round (bp_gens_fold_tables; ipa.cuh k_ipa_fold_tab)
     DevBuf ftab_G, ftab_H;
     size_t ftab_n = 0;       // bases covered: G[0..ftab_n), H[0..ftab_n)
@@ -417,6 +424,160 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (mtrace) fprintf(stderr, "[msm] n=%zu c=%d W=%d K=%d  front(enqueue+sync) %.1f us  back enqueue %.1f us  back wait %.1f us  host tail %.1f us\n", n, pl.c, pl.W, K,
                         (t_m1 - t_m0) * 1e6, (t_m2 - t_m1) * 1e6, (t_m3 - t_m2) * 1e6, (tnow() - t_m3) * 1e6);
     return finish_sharded(result);
+}
+
+// ---- fixed-base MSM over the generator tables (msm.cuh 1c) -----------------------------------------------------------------
+static constexpr u32 FB_ROWS = 65;   // rows at bit positions 0, 4, 8, .., 256: any window width c that is a multiple of 4 finds its rows (the last one serves the carry window)
+// A run of generator-table bases of a fixed-base MSM: which table (0 = G, 1 = H, 2 = PedersenGens {B, B_blinding}), first index, count
+struct FbRun { int table; size_t first, count; };
+template <class C> static int fb_tables_build(bp_ctx* ctx, size_t cap) {
+    hipStream_t st = ctx->stream;
+    if (cap == 0 || cap > ctx->gens_cap) { g_err = "msm tables: more bases than installed generators"; return BP_E_GENS_LENGTH; }
+    if (!ctx->d_G.owned) { g_err = "msm tables: build them on the ctx that owns the generator tables, then bp_gens_share"; return BP_E_ARG; }
+    ctx->fb_cap = 0;
+    BPCHK(ctx->fb_G.ensure((size_t)FB_ROWS * cap * 64)); BPCHK(ctx->fb_H.ensure((size_t)FB_ROWS * cap * 64)); BPCHK(ctx->fb_pc.ensure((size_t)FB_ROWS * 2 * 64));
+    const size_t slab = std::min<size_t>(cap, (size_t)1 << 18);   // bounds the Jacobian scratch: 65 rows x 2^18 x 96 B = 1.6 GB
+    DevBuf tmp, pref, outb;
+    BPCHK(tmp.ensure(FB_ROWS * slab * 96)); BPCHK(pref.ensure(FB_ROWS * slab * 32)); BPCHK(outb.ensure(FB_ROWS * slab * 64));
+    auto build = [&](const u32* gens, u32* table, size_t count, size_t table_cap) -> int {
+        for (size_t lo = 0; lo < count; lo += slab) {
+            const size_t m = std::min(slab, count - lo);
+            const u32 gb = (u32)((m + 255) / 256);
+            hipLaunchKernelGGL(k_msm_fb_rows<C>, dim3(gb), dim3(256), 0, st, gens + lo * 16, tmp.as<u32>(), (u32)m, FB_ROWS);
+            hipLaunchKernelGGL(k_ftab_normalize<C>, dim3(gb), dim3(256), 0, st, tmp.as<u32>(), pref.as<u32>(), outb.as<u32>(), (u32)m, FB_ROWS);
+            HIPCHK(hipGetLastError());
+            for (u32 r = 0; r < FB_ROWS; r++)   // [r][i] of the slab -> [r][lo + i] of the table
+                HIPCHK(hipMemcpyAsync(table + ((size_t)r * table_cap + lo) * 16, outb.as<u32>() + (size_t)r * m * 16, m * 64, hipMemcpyDeviceToDevice, st));
+        }
+        return BP_OK;
+    };
+    BPCHK(build(ctx->d_G.as<u32>(), ctx->fb_G.as<u32>(), cap, cap));
+    BPCHK(build(ctx->d_H.as<u32>(), ctx->fb_H.as<u32>(), cap, cap));
+    BPCHK(build(ctx->d_pc.as<u32>(), ctx->fb_pc.as<u32>(), 2, 2));
+    HIPCHK(hipStreamSynchronize(st));
+    tmp.release(); pref.release(); outb.release();
+    ctx->fb_cap = cap;
+    return BP_OK;
+}
+// sum_t s_t * Base(t) for bases given as runs of the generator tables; *done = false when the fixed-base path does not apply
+// (no tables, a run beyond them, skewed scalars overflowing a bin region, window-sharded ctx): the caller then runs the
+// ordinary MSM over the same bases.
+template <class C>
+static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSegs& ssegs, size_t n, int scalars_mont, J4& result, bool& done) {
+    typedef host::Grp<C> G;
+    done = false;
+    static const bool off = getenv("ARKBP_MSM_NOFIXED") != nullptr;   // A/B switch
+    if (off || !ctx->fb_cap || ctx->shard_world > 1 || n < 4096 || n >= ((size_t)1 << 24) || nruns > MSM_MAXSEG) return BP_OK;
+    BaseSegs segs; memset(&segs, 0, sizeof segs);
+    u32 at = 0;
+    for (int k = 0; k < nruns; k++) {
+        const size_t cap = runs[k].table == 2 ? 2 : ctx->fb_cap;
+        if (runs[k].first + runs[k].count > cap) return BP_OK;
+        const DevBuf& tb = runs[k].table == 0 ? ctx->fb_G : runs[k].table == 1 ? ctx->fb_H : ctx->fb_pc;
+        segs.ptr[k] = (const u32*)tb.p + runs[k].first * 16;
+        segs.row_words[k] = (u64)cap * 16;
+        segs.start[k] = at; at += (u32)runs[k].count;
+    }
+    segs.start[nruns] = at; segs.nseg = nruns;
+    if (at != n) { g_err = "msm_fixed: runs and term count differ"; return BP_E_ARG; }
+    hipStream_t st = ctx->stream;
+    // window width: a multiple of 4 (the table rows); cost = mixed adds (n * W) + bucket aggregation (~6 add-equivalents per bucket)
+    const int bits = C::Fr::BITS;
+    int bc = 8; double best = 1e300;
+    for (int c = 8; c <= 24; c += 4) {
+        const double W = bits / c + 1, NBk = std::ldexp(1.0, c - 1);
+        const double cost = n * W * 1.1 + NBk * 6.0;
+        if (cost < best) { best = cost; bc = c; }
+    }
+    static const int c_env = getenv("ARKBP_MSM_FIXED_C") ? atoi(getenv("ARKBP_MSM_FIXED_C")) : 0;
+    if (c_env >= 8 && c_env <= 24 && c_env % 4 == 0) bc = c_env;
+    MsmPlan pl; pl.c = bc; pl.W = bits / bc + 1; pl.NB = 1 << (bc - 1); pl.B = (u32)pl.NB; pl.n = (u32)n; pl.w_lo = 0; pl.w_hi = pl.W;
+    if ((u32)(pl.W - 1) * (u32)(bc / 4) >= FB_ROWS) return BP_OK;
+    u32 tbits = 1; while (((size_t)1 << tbits) < n) tbits++;   // (term indices are < n: n itself need not fit)
+    u32 wbits = 1; while ((1 << wbits) < pl.W) wbits++;
+    const u32 vbits = tbits + wbits;
+    // bins: ~6 K entries each; the entry word must hold vterm | fine bucket | sign
+    const double entries = (double)n * (pl.W - 1) + (double)n * 0.5;
+    u32 nbin = 1, lg = 0;
+    while ((double)nbin * 6000.0 < entries && nbin < (u32)pl.NB) { nbin <<= 1; lg++; }
+    int LB = bc - 1 - (int)lg;
+    while (LB > 0 && (LB > 11 || vbits + (u32)LB + 1 > 32)) { nbin <<= 1; LB--; }
+    if (vbits + (u32)LB + 1 > 32 || (size_t)nbin * 4 > 64 * 1024) return BP_OK;
+    // expected load of the fullest bin: every full window spreads n(1 - 2^-c) digits uniformly; the top window (tb bits) only reaches
+    // the lowest 2^(tb-1) buckets
+    const int tb = bits - bc * (pl.W - 1);
+    double mu = (double)n * (pl.W - 1) / nbin;
+    if (tb > 0) { const double reach = std::max(1.0, std::ldexp(1.0, tb - 1) / (double)((u32)1 << LB)); mu += (double)n / std::min<double>(reach, nbin); }
+    const size_t cap = (size_t)(mu + 8.0 * std::sqrt(mu) + 64.0);
+    if ((((size_t)1 << LB) + 4 + cap) * 4 > 64 * 1024 || (size_t)nbin * cap >= ((size_t)1 << 31)) return BP_OK;
+    BinPlan bp; memset(&bp, 0, sizeof bp);
+    bp.LB = (u32)LB; bp.NBIN = nbin; bp.cap = (u32)cap; bp.wb = 1; bp.tpt = (u32)std::min<size_t>(16, std::max<size_t>(1, n / (256 * 512)));
+    SlotPlan sp; memset(&sp, 0, sizeof sp);
+    constexpr int NL = MSM_NLMAX;
+    int nl = 2;
+    { u64 capl = MSM_CH; while (capl < entries + 1 && nl < NL) { capl *= MSM_CH; nl++; } }
+    if (nl < 4) nl = 4;
+    const size_t Bp1 = (size_t)pl.B + 1;
+    const u32 ntiles = (pl.B + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
+    const u32 nblk_ws = (u32)((pl.NB + 256 * MSM_SEG - 1) / (256 * MSM_SEG));
+    BPCHK(ctx->canon.ensure(n * 32)); BPCHK(ctx->hist.ensure((size_t)pl.B * 4)); BPCHK(ctx->lvl_off.ensure(Bp1 * NL * 4));
+    BPCHK(ctx->totals.ensure((NL + 2) * 4 + (size_t)ntiles * (NL + 1) * 4)); BPCHK(ctx->bin_cur.ensure((size_t)nbin * 4)); BPCHK(ctx->boff.ensure((size_t)pl.B * 4));
+    BPCHK(ctx->slots.ensure((size_t)nbin * cap * 4)); BPCHK(ctx->Tbuf.ensure(((size_t)nblk_ws + 1) * 96));
+    if (!ctx->h_totals) HIPCHK(hipHostMalloc((void**)&ctx->h_totals, 64));
+    if (ctx->h_T_cap < 96) { if (ctx->h_T) HIPCHK(hipHostFree(ctx->h_T)); HIPCHK(hipHostMalloc((void**)&ctx->h_T, 4096)); ctx->h_T_cap = 4096; }
+    ScopedK total(ctx, BP_K_MSM_TOTAL);
+    u32* lvl = ctx->lvl_off.as<u32>();
+    u32* d_tot = ctx->totals.as<u32>();
+    u32* d_tiles = d_tot + (NL + 2);
+    u32* d_over = d_tot + (NL + 1);
+    const int chl = MSM_CHL_BINNED;
+    HIPCHK(hipMemsetAsync(d_over, 0, 4, st));
+    HIPCHK(hipMemsetAsync(ctx->bin_cur.p, 0, (size_t)nbin * 4, st));
+    const u32 gp = (u32)((n + (size_t)256 * bp.tpt - 1) / ((size_t)256 * bp.tpt));
+    hipLaunchKernelGGL(k_msm_fb_partition<C>, dim3(gp), dim3(256), (size_t)nbin * 4, st, ssegs, ctx->canon.as<u32>(), pl, scalars_mont, bp, tbits, ctx->bin_cur.as<u32>(),
+                       ctx->slots.as<u32>(), d_over);
+    MsmPlan pl1 = pl; pl1.W = 1;   // one bucket set from here on
+    hipLaunchKernelGGL(k_msm_bin_sort, dim3(nbin, 1), dim3(256), (((size_t)1 << LB) + 4 + cap) * 4, st, ctx->slots.as<u32>(), ctx->bin_cur.as<u32>(), ctx->hist.as<u32>(),
+                       ctx->boff.as<u32>(), pl1, bp, sp);
+    hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl, chl, pl.B, 1);
+    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
+    hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl, chl, pl.B, 1);
+    HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    const u32* tot = ctx->h_totals;
+    if (tot[NL + 1] != 0) { total.stop(); return BP_OK; }   // a bin region overflowed (skewed scalars): the ordinary MSM handles those
+    result = G::inf();
+    done = true;
+    if (tot[0] == 0) { total.stop(); return BP_OK; }
+    const u32 maxcnt = tot[NL];
+    int K = 1;
+    { u64 capl = (u64)1 << chl; while (capl < maxcnt) { capl <<= chl; K++; } }
+    if (K >= nl) { done = false; total.stop(); return BP_OK; }
+    BPCHK(ctx->lvA.ensure((size_t)tot[1] * 96));
+    if (K >= 2) BPCHK(ctx->lvB.ensure((size_t)tot[2] * 96));
+    segs.fixed_c4 = (u32)(bc / 4); segs.tbits = tbits;
+    {
+        ScopedK acc(ctx, BP_K_MSM_ACCUM);
+        hipLaunchKernelGGL(k_msm_accum<C>, dim3((tot[1] + 255) / 256), dim3(256), 0, st, segs, ctx->slots.as<u32>(), lvl, lvl + Bp1, ctx->lvA.as<u32>(), pl.B, tot[1], 2, sp,
+                           (u32)pl.NB, ctx->boff.as<u32>(), chl);
+    }
+    u32* cur = ctx->lvA.as<u32>();
+    u32* nxt = ctx->lvB.as<u32>();
+    for (int k = 2; k <= K; k++) {
+        hipLaunchKernelGGL(k_msm_reduce<C>, dim3((tot[k] + 255) / 256), dim3(256), 0, st, cur, lvl + Bp1 * (k - 1), lvl + Bp1 * k, nxt, pl.B, tot[k], chl, pl.B);
+        u32* t2 = cur; cur = nxt; nxt = t2;
+    }
+    hipLaunchKernelGGL(k_msm_window_sums<C>, dim3(nblk_ws, 1), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl1, nblk_ws);
+    hipLaunchKernelGGL(k_msm_sum_partials<C>, dim3(1), dim3(256), 0, st, ctx->Tbuf.as<u32>(), nblk_ws, ctx->Tbuf.as<u32>() + (size_t)nblk_ws * 24);
+    HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.as<u32>() + (size_t)nblk_ws * 24, 96, hipMemcpyDeviceToHost, st));
+    total.stop();
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    const u64* T = (const u64*)ctx->h_T;
+    J4 pnt; memcpy(pnt.X.v, T, 32); memcpy(pnt.Y.v, T + 4, 32); memcpy(pnt.Z.v, T + 8, 32);
+    if (!pnt.Z.is_zero()) result = pnt;   // no Horner tail: the rows already carry the powers of two
+    return BP_OK;
 }
 
 // MSM over the resident generator tables (no base upload): bases = G[off..off+n) (if use_G) || H[off..off+n) (if use_H) || extras
@@ -708,8 +869,8 @@ template <class C> static int ipa_begin_dev(bp_ctx* ctx, IpaState& s, const u32*
     if (rho_pw && d_rho_pow) { s.have_rho = true; s.rho_pw = rho_pw; s.d_rho_pow = d_rho_pow; }
     s.allow_freeze = allow_freeze;
     const size_t fz = std::max<size_t>(ctx->tune_ipa_freeze_len, 2);
-    BPCHK(ctx->ipa_sL.ensure((std::max(n, 2 * fz) + 1) * 32));
-    BPCHK(ctx->ipa_sR.ensure((std::max(n, 2 * fz) + 1) * 32));
+    BPCHK(ctx->ipa_sL.ensure((std::max(n, 2 * fz) + 2) * 32));
+    BPCHK(ctx->ipa_sR.ensure((std::max(n, 2 * fz) + 2) * 32));
     BPCHK(ctx->ipa_part.ensure(((std::max(n / 2, fz) + 255) / 256 + 1) * 64));
     return BP_OK;
 }
@@ -729,7 +890,7 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
         {
             ScopedK tk(ctx, BP_K_IPA_SCALARS);
             hipLaunchKernelGGL(k_ipa_frozen_scalars<C>, dim3(gf), dim3(256), 0, st, s.d_a, s.d_b, s.d_cG, s.d_cH, (u32)n, (u32)n0, sL, sR, ctx->ipa_part.as<u32>());
-            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gf, sL + 2 * n0 * 8, sR + 2 * n0 * 8);
+            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gf, sL + 2 * n0 * 8, sR + 2 * n0 * 8, words_of<S>(s.qw), 0);
         }
         BaseSegs sg; memset(&sg, 0, sizeof sg);
         sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n0; sg.start[2] = (u32)(2 * n0); sg.start[3] = (u32)(2 * n0 + 1);
@@ -747,7 +908,29 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
         ScopedK tk(ctx, BP_K_IPA_SCALARS);
         hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, s.d_Gf, s.d_Hf, s.first ? 1 : 0, (u32)n, sL, sR, ctx->ipa_part.as<u32>(),
                            s.pending ? (s.h_geo ? 2 : 1) : 0, words_of<S>(s.gamma_G), words_of<S>(s.gamma_H), s.d_rho_pow);
-        hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8);
+        hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8, words_of<S>(s.qw), s.have_qw ? 1 : 0);
+    }
+    if (s.d_G_in && s.have_qw && s.msm_mode == -1) {
+        // round 1 over the resident generator tables with Q = qw * B: fixed-base MSMs (c_L * Q = (c_L * qw) * B, the scaled
+        // inner products are in slot 2n + 1).  L = <xl, G[n..2n)> + <yl, H[0..n)> + c_L Q,  R = <xr, G[0..n)> + <yr, H[n..2n)> + c_R Q.
+        const size_t gofs = (size_t)(s.d_G_in - ctx->d_G.as<u32>()) / 16, hofs = (size_t)(s.d_H_in - ctx->d_H.as<u32>()) / 16;
+        J4 Lj, Rj; bool dl = false, dr = false;
+        ScalSegs ss; memset(&ss, 0, sizeof ss);
+        ss.nseg = 2; ss.ptr[0] = sL; ss.start[0] = 0; ss.start[1] = (u32)(2 * n); ss.ptr[1] = sL + (2 * n + 1) * 8; ss.start[2] = (u32)(2 * n + 1);
+        FbRun rl[3] = {{0, gofs + n, n}, {1, hofs, n}, {2, 0, 1}};
+        BPCHK(msm_fixed_run<C>(ctx, rl, 3, ss, 2 * n + 1, 0, Lj, dl));
+        if (dl) {
+            ss.ptr[0] = sR; ss.ptr[1] = sR + (2 * n + 1) * 8;
+            FbRun rr[3] = {{0, gofs, n}, {1, hofs + n, n}, {2, 0, 1}};
+            BPCHK(msm_fixed_run<C>(ctx, rr, 3, ss, 2 * n + 1, 0, Rj, dr));
+        }
+        if (dl && dr) {
+            A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
+            memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
+            memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
+            s.lr_done = true;
+            return BP_OK;
+        }
     }
     BaseSegs sg; memset(&sg, 0, sizeof sg);
     sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n; sg.start[2] = (u32)(2 * n); sg.start[3] = (u32)(2 * n + 1);
@@ -882,12 +1065,14 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                                                         rho_pw[k] = rho^-(2^k), rho_pw[32+k] = rho^(2^k), k < 32 */,
                           const u32* d_rho_pow = nullptr /* device table of rho^(2^k), resident words */,
                           bool gens_are_tables = false /* d_G, d_H stand for the ctx's generator tables G[0..n), H[0..n) */,
-                          bool gens_in_place = false /* ... and were NOT copied: round 1 reads ctx->d_G / d_H, d_G / d_H receive its output */) {
+                          bool gens_in_place = false /* ... and were NOT copied: round 1 reads ctx->d_G / d_H, d_G / d_H receive its output */,
+                          const F4* q_scalar = nullptr /* Q = q_scalar * B (PedersenGens::B) */) {
     IpaState s;
     BPCHK(ipa_begin_dev<C>(ctx, s, d_Q, d_Gf, d_Hf, d_G, d_H, d_a, d_b, n, gf_halves, rho_pw, d_rho_pow, true));
     if (gens_are_tables) { s.gens_first = 0; s.gens_stride = 1; }
     if (gens_in_place) { s.d_G_in = ctx->d_G.as<u32>(); s.d_H_in = ctx->d_H.as<u32>(); }
     if (n == 1) s.d_G_in = s.d_H_in = nullptr;
+    if (q_scalar) { s.have_qw = true; s.qw = *q_scalar; }
     while (s.n != 1) {
         uint64_t Lw[8], Rw[8], uw[4];
         BPCHK(ipa_round_lr<C>(ctx, s, Lw, Rw));
@@ -1316,7 +1501,7 @@ template <class C> static int dbg_inner_product(bp_ctx* ctx, const uint64_t* a, 
     Words8 zero; memset(&zero, 0, sizeof zero);
     hipLaunchKernelGGL(k_ipa_scalars<C>, dim3(gb), dim3(256), 0, st, ctx->ipa_a.as<u32>(), ctx->ipa_b.as<u32>(), ctx->ipa_Gf.as<u32>(), ctx->ipa_Hf.as<u32>(), 0, (u32)n, sL, sR,
                        ctx->ipa_part.as<u32>(), 0, zero, zero, (const u32*)nullptr);
-    hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8);
+    hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 2 * n * 8, sR + 2 * n * 8, zero, 0);
     HIPCHK(hipGetLastError());
     uint64_t canon[4];
     HIPCHK(hipMemcpyAsync(canon, sL + 2 * n * 8, 32, hipMemcpyDeviceToHost, st));
@@ -1482,13 +1667,14 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
-                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->cyc_a, &c->cyc_b, &c->cyc_Gf, &c->cyc_Hf, &c->ftab_G, &c->ftab_H, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab};
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->cyc_a, &c->cyc_b, &c->cyc_Gf, &c->cyc_Hf, &c->ftab_G, &c->ftab_H, &c->fb_G, &c->fb_H, &c->fb_pc, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab};
     c->templates.clear();
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
     for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); if (c->dec_ev[i]) (void)hipEventDestroy(c->dec_ev[i]); }
     for (int i = 0; i < 2; i++) if (c->h_vaux[i]) (void)hipHostFree(c->h_vaux[i]);
+    if (c->h_upload) (void)hipHostFree(c->h_upload);
     if (c->h_dec) (void)hipHostFree(c->h_dec);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     (void)hipStreamDestroy(c->stream);
@@ -1662,6 +1848,15 @@ int bp_gens_upload(bp_ctx* c, const uint64_t* G_xy, const uint64_t* H_xy, size_t
     if (!c || !G_xy || !H_xy || !cap) return BP_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     return c->curve == 0 ? gens_install<Secq>(c, G_xy, H_xy, cap) : gens_install<Zorro>(c, G_xy, H_xy, cap);
+}
+int bp_gens_msm_tables(bp_ctx* c, size_t count, size_t* bytes_out) {
+    if (!c) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (count == 0) { if (c->fb_G.owned) { c->fb_G.release(); c->fb_H.release(); c->fb_pc.release(); } c->fb_cap = 0; return BP_OK; }
+    const int rc = c->curve == 0 ? fb_tables_build<Secq>(c, count) : fb_tables_build<Zorro>(c, count);
+    if (rc) return rc;
+    if (bytes_out) *bytes_out = 2 * (size_t)FB_ROWS * count * 64;
+    return BP_OK;
 }
 int bp_gens_fold_tables(bp_ctx* c, size_t count, int window_bits, size_t budget_bytes, int* window_bits_out, size_t* bytes_out) {
     if (!c || window_bits < 0 || window_bits == 1 || window_bits > 8) return BP_E_ARG;
@@ -1975,9 +2170,10 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src) {
     DevBuf* sr[] = {&src->d_G, &src->d_H, &src->d_pc};
     for (int i = 0; i < 3; i++) { d[i]->release(); d[i]->p = sr[i]->p; d[i]->cap = sr[i]->cap; d[i]->owned = false; }
     dst->gens_cap = src->gens_cap; dst->pc_B = src->pc_B; dst->pc_Bb = src->pc_Bb;
-    DevBuf* dt[] = {&dst->ftab_G, &dst->ftab_H};
-    DevBuf* stb[] = {&src->ftab_G, &src->ftab_H};
-    for (int i = 0; i < 2; i++) { dt[i]->release(); dt[i]->p = stb[i]->p; dt[i]->cap = stb[i]->cap; dt[i]->owned = false; }
+    DevBuf* dt[] = {&dst->ftab_G, &dst->ftab_H, &dst->fb_G, &dst->fb_H, &dst->fb_pc};
+    DevBuf* stb[] = {&src->ftab_G, &src->ftab_H, &src->fb_G, &src->fb_H, &src->fb_pc};
+    for (int i = 0; i < 5; i++) { dt[i]->release(); dt[i]->p = stb[i]->p; dt[i]->cap = stb[i]->cap; dt[i]->owned = false; }
+    dst->fb_cap = src->fb_cap;
     dst->ftab_n = src->ftab_n; dst->ftab_w = src->ftab_w; dst->ftab_nwin = src->ftab_nwin;
     return BP_OK;
 }

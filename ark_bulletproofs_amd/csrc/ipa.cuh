@@ -135,7 +135,7 @@ k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* _
     }
 }
 template <class C> __global__ void __launch_bounds__(256)
-k_ipa_ip_finish(const u32* __restrict__ partials, u32 nparts, u32* __restrict__ outL, u32* __restrict__ outR) {
+k_ipa_ip_finish(const u32* __restrict__ partials, u32 nparts, u32* __restrict__ outL, u32* __restrict__ outR, Words8 qw, int with_qw) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
     Fe pl = fe_zero<F>(), pr = fe_zero<F>();
@@ -148,6 +148,11 @@ k_ipa_ip_finish(const u32* __restrict__ partials, u32 nparts, u32* __restrict__ 
     if (threadIdx.x == 0) {
         store_fe_canon<F>(outL, pl);
         store_fe_canon<F>(outR, pr);
+        if (with_qw) {   // Q = qw * B: the scalars of B for a fixed-base round (slot after the inner products)
+            const Fe q = fe_load_ark<F>(qw.w);
+            store_fe_canon<F>(outL + 8, fe_mul<F>(pl, q));
+            store_fe_canon<F>(outR + 8, fe_mul<F>(pr, q));
+        }
     }
 }
 

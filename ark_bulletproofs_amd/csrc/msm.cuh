@@ -39,12 +39,19 @@ struct BaseSegs {
     const u32* ptr[MSM_MAXSEG];   // 16 words per point, packed R' form (aff_store_dev)
     u32 start[MSM_MAXSEG + 1];    // prefix counts; start[nseg] = n
     int nseg;
+    // fixed-base mode (the bases are generator tables with precomputed rows, see k_msm_fb_partition): ptr[k] names row 0 of
+    // segment k's table, row r (= 2^(4r) * base) lies row_words[k] * r words further; an entry's term field is (window << tbits) | term
+    u32 fixed_c4;                 // window bits / 4 (0 = ordinary MSM)
+    u32 tbits;
+    u64 row_words[MSM_MAXSEG];
 };
 __device__ __forceinline__ const u32* seg_base_ptr(const BaseSegs& s, u32 idx) {
+    u32 w = 0;
+    if (s.fixed_c4) { w = idx >> s.tbits; idx &= (1u << s.tbits) - 1u; }
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MSM_MAXSEG; j++) k += (j < s.nseg && idx >= s.start[j]) ? 1 : 0;
-    return s.ptr[k] + (size_t)(idx - s.start[k]) * 16;
+    return s.ptr[k] + (size_t)(idx - s.start[k]) * 16 + (size_t)(w * s.fixed_c4) * s.row_words[k];
 }
 
 // The scalar vector of an MSM, likewise: up to 4 device-resident runs (e.g. blinding || a_L || a_R of a commitment,
@@ -320,6 +327,74 @@ k_msm_bin_sort(u32* __restrict__ ent, const u32* __restrict__ bin_cur, u32* __re
     }
 }
 
+// 1c. Fixed-base MSM over generator tables.  BulletproofGens never change, and 7/9 of a proof's MSM terms are over them (the
+// commitments A_I, A_O, S and the first round's L, R; src/r1cs/prover.rs:516-559, src/inner_product_proof.rs:83-131).  With the
+// rows 2^(c*w) * P_i precomputed (bp_gens_msm_tables), sum_i s_i P_i = sum_i sum_w d_iw * (2^(c*w) P_i): EVERY window's digits
+// fall into ONE shared bucket set of 2^(c-1) buckets — W * n (digit, table-row) pairs sorted by |digit| alone.  The per-window
+// costs (bucket aggregation, W * c doublings of the Horner tail) are paid once instead of W times, so the window can be wide
+// (c = 20 at 2^21 terms: 13 mixed adds per term instead of 17-18) and the result needs no doublings at all.
+// This kernel is k_msm_bin_partition for that layout: bin regions are per bin (not per window), an entry is
+// (((window << tbits) | term) << (LB+1)) | (fine bucket << 1) | sign.
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_fb_partition(ScalSegs scalars, u32* __restrict__ canon, MsmPlan pl, int scalars_mont, BinPlan bp, u32 tbits, u32* __restrict__ bin_cur,
+                   u32* __restrict__ ent, u32* __restrict__ overflow) {
+    typedef typename C::Fr Fr;
+    extern __shared__ u32 lds_cnt[];   // NBIN bin counters
+    for (u32 x = threadIdx.x; x < bp.NBIN; x += 256) lds_cnt[x] = 0;
+    __syncthreads();
+    const u32 tile0 = blockIdx.x * 256u * bp.tpt;
+    for (u32 t = 0; t < bp.tpt; t++) {
+        const u32 i = tile0 + t * 256u + threadIdx.x;
+        if (i >= pl.n) break;
+        u32 k[8];
+        load_words8(k, seg_scalar_ptr(scalars, i));
+        if (scalars_mont == 1) { Fe s = fe_load_ark<Fr>(k); fe_store_canon<Fr>(k, s); }
+        else if (scalars_mont == 2) { Fe s = fe_unpack(k); fe_store_canon<Fr>(k, s); }
+        store_words8(canon + (size_t)i * 8, k);
+        u32 carry = 0;
+        for (int w = 0; w < pl.W; w++) {
+            const int d = msm_digit(k, w, pl.c, carry);
+            if (d == 0) continue;
+            const u32 v = (u32)(d < 0 ? -d : d) - 1;
+            atomicAdd(&lds_cnt[v >> bp.LB], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 x = threadIdx.x; x < bp.NBIN; x += 256) {
+        const u32 cn = lds_cnt[x];
+        if (cn) lds_cnt[x] = atomicAdd(&bin_cur[x], cn);
+    }
+    __syncthreads();
+    const u32 fmask = (1u << bp.LB) - 1u;
+    for (u32 t = 0; t < bp.tpt; t++) {
+        const u32 i = tile0 + t * 256u + threadIdx.x;
+        if (i >= pl.n) break;
+        u32 k[8];
+        load_words8(k, canon + (size_t)i * 8);
+        u32 carry = 0;
+        for (int w = 0; w < pl.W; w++) {
+            const int d = msm_digit(k, w, pl.c, carry);
+            if (d == 0) continue;
+            const u32 v = (u32)(d < 0 ? -d : d) - 1;
+            const u32 bin = v >> bp.LB;
+            const u32 pos = atomicAdd(&lds_cnt[bin], 1u);
+            if (pos < bp.cap) ent[(size_t)bin * bp.cap + pos] = ((((u32)w << tbits) | i) << (bp.LB + 1)) | ((v & fmask) << 1) | (d < 0 ? 1u : 0u);
+            else *overflow = 1u;
+        }
+    }
+}
+// rows of a fixed-base table: tmp[r * n + i] = 2^(4r) * P_i (Jacobian), r < R
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_fb_rows(const u32* __restrict__ gens, u32* __restrict__ tmp, u32 n, u32 R) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Jac acc = jac_madd<C>(jac_inf<C>(), load_aff_dev(gens + (size_t)i * 16));
+#pragma unroll 1
+    for (u32 r = 0; r < R; r++) {
+        store_jac_ws<C>(tmp + ((size_t)r * n + i) * 24, acc);
+        acc = jac_dbl<C>(jac_dbl<C>(jac_dbl<C>(jac_dbl<C>(acc))));
+    }
+}
 // 2. scans.  lvl_off[k] (k = 0..nl-1) has B+1 entries: level 0 counts entries, level k >= 1 counts
 // ceil(cnt / CH^k) chunks.  totals[k] = lvl_off[k][B]; totals[NLMAX] = max bucket population.
 // Three launches: per-tile sums, one-workgroup scan of the tile sums, per-tile exclusive scan.
@@ -636,6 +711,35 @@ k_msm_window_sums(const u32* __restrict__ sums, const u32* __restrict__ off, u32
         fe_store_ark<F>(wd, contrib.Y); store_words8(o + 8, wd);
         if (inf) { for (int i = 0; i < 8; i++) wd[i] = 0; } else fe_store_ark<F>(wd, contrib.Z);
         store_words8(o + 16, wd);
+    }
+}
+
+// sum of `count` Jacobian points given as ark Montgomery words (the partials of k_msm_window_sums) -> out (same form), one workgroup
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_sum_partials(const u32* __restrict__ T_in, u32 count, u32* __restrict__ T_out) {
+    typedef typename C::Fq F;
+    __shared__ u32 sh[256 * 27];
+    Jac acc = jac_inf<C>();
+    for (u32 j = threadIdx.x; j < count; j += 256) {
+        u32 w[8];
+        Jac p;
+        load_words8(w, T_in + (size_t)j * 24); p.X = fe_load_ark<F>(w);
+        load_words8(w, T_in + (size_t)j * 24 + 8); p.Y = fe_load_ark<F>(w);
+        load_words8(w, T_in + (size_t)j * 24 + 16);
+        bool z = true;
+        for (int q = 0; q < 8; q++) z = z && w[q] == 0;
+        if (z) continue;
+        p.Z = fe_load_ark<F>(w);
+        acc = jac_add<C>(acc, p);
+    }
+    acc = block_sum_jac<C>(acc, sh);
+    if (threadIdx.x == 0) {
+        u32 wd[8];
+        const bool inf = jac_is_inf(acc);
+        fe_store_ark<F>(wd, acc.X); store_words8(T_out, wd);
+        fe_store_ark<F>(wd, acc.Y); store_words8(T_out + 8, wd);
+        if (inf) { for (int i = 0; i < 8; i++) wd[i] = 0; } else fe_store_ark<F>(wd, acc.Z);
+        store_words8(T_out + 16, wd);
     }
 }
 

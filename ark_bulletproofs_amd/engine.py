@@ -797,3 +797,14 @@ def _gens_fold_tables(self, count, window_bits=0, budget_bytes=0):
 
 
 Engine.gens_fold_tables = _gens_fold_tables
+
+
+def _gens_msm_tables(self, count):
+    """fixed-base rows of G[0..count), H[0..count) and PedersenGens for the prover's MSMs over the generator tables
+    (bp_gens_msm_tables); returns the table bytes"""
+    nbytes = C.c_size_t(0)
+    check(lib().bp_gens_msm_tables(self.ctx, C.c_size_t(count), C.byref(nbytes)), "bp_gens_msm_tables")
+    return nbytes.value
+
+
+Engine.gens_msm_tables = _gens_msm_tables

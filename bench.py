@@ -370,6 +370,12 @@ def run_prove(args, rank, world, local):
         t0 = time.perf_counter()
         wbits, nbytes = engs[0].gens_fold_tables(N // 2, window_bits=args.fold_table_bits)
         tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0}
+    msm_tab_info = None
+    if args.msm_tables and not window_sharded:
+        # fixed-base rows of the generators for the MSMs over the tables themselves (commitments, first-round L / R)
+        t0 = time.perf_counter()
+        nbytes = engs[0].gens_msm_tables(N)
+        msm_tab_info = {"GB": nbytes / 1e9, "build_s": time.perf_counter() - t0}
     for e in engs[1:]:
         e.share_gens_from(engs[0])
     if window_sharded:
@@ -418,7 +424,7 @@ def run_prove(args, rank, world, local):
                                % (args.logn, CURVES[args.curve], args.batch, P, args.host_threads, args.build_threads),
                    "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "build_threads": args.build_threads,
                    "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
-                   "pipeline_thread_seconds_per_wall_second": pipe_util, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info,
+                   "pipeline_thread_seconds_per_wall_second": pipe_util, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
     if fold_n:
@@ -585,12 +591,13 @@ def main():
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
     ap.add_argument("--cpu-verify-proofs", type=int, default=256, help="CPU baseline sample of the verify workload (about 10 s)")
     ap.add_argument("--batch", type=int, default=16, help="independent proofs per step per GPU (prove workload)")
-    ap.add_argument("--host-threads", type=int, default=3, help="host threads running the TranscriptRng head of prove()")
-    ap.add_argument("--build-threads", type=int, default=3, help="host threads constructing statements (Prover::new + commit + gadget)")
-    ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
+    ap.add_argument("--host-threads", type=int, default=5, help="host threads running the TranscriptRng head of prove()")
+    ap.add_argument("--build-threads", type=int, default=8, help="host threads constructing statements (Prover::new + commit + gadget)")
+    ap.add_argument("--inflight", type=int, default=12, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--window", type=int, default=64, help="statements alive at once in the prove pipeline (built, waiting for or in the TranscriptRng stage, "
                     "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s")
     ap.add_argument("--fold-tables", type=int, default=1, help="prove workload: fixed-base tables of the generators for the first fold round (0 = off)")
+    ap.add_argument("--msm-tables", type=int, default=1, help="prove workload: fixed-base rows of the generators for the MSMs over the tables themselves (0 = off)")
     ap.add_argument("--fold-table-bits", type=int, default=0, help="window width of those tables (0 = the widest that fits in 3/4 of the free HBM)")
     ap.add_argument("--terms", type=int, default=1 << 16)
     ap.add_argument("--shard", default="terms", choices=["terms", "windows"],

@@ -153,6 +153,13 @@ int bp_gens_download(bp_ctx* ctx, uint64_t* G_xy, uint64_t* H_xy, size_t n);
  * choice and the table size come back in *window_bits_out / *bytes_out (2^19 bases, w = 8: 146 GB for both vectors on secq256k1).
  * Built on the ctx that owns the generators; bp_gens_share hands them on.  count = 0 frees them.  Results never depend on it. */
 int bp_gens_fold_tables(bp_ctx* ctx, size_t count, int window_bits, size_t budget_bytes, int* window_bits_out, size_t* bytes_out);
+/* Optional: fixed-base rows 2^(4r) * G[i], 2^(4r) * H[i] (r < 64, i < count) and the same for PedersenGens, 4 KiB per generator
+ * (count = 2^20: 8.6 GB).  With them every MSM the prover runs over the generator tables themselves — the commitments A_I, A_O, S
+ * (src/r1cs/prover.rs:516-559, 604-649) and the first round's L, R (src/inner_product_proof.rs:83-131), 7/9 of a proof's MSM
+ * terms — sorts the digits of ALL Pippenger windows into ONE bucket set (the row supplies the power of two): the per-window costs
+ * are paid once, the window is wider (c = 20 at 2^21 terms: 13 mixed adds per term instead of 17-18) and the result needs no
+ * doublings.  Skewed scalars (0/1 witness vectors) fall back to the ordinary schedule.  Results never depend on it. */
+int bp_gens_msm_tables(bp_ctx* ctx, size_t count, size_t* bytes_out);
 /* PedersenGens::default() -> (B, B_blinding); host only */
 int bp_pedersen_gens(int curve, uint64_t B_xy[8], uint64_t B_blinding_xy[8]);
 /* GeneratorsChain for label 'G'|'H' || LE32(party) (src/generators.rs:71-121), first `count` points; host only */

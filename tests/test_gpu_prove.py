@@ -277,3 +277,24 @@ def test_prove_with_first_round_fold_tables(oracle, w):
         e.gens_fold_tables(0)
         assert e.prove_scenario(3, [300, 0], SEED, m_cap=8).proof == ref.proof
         e.close()
+
+
+@pytest.mark.parametrize("fold_tables", [False, True])
+def test_prove_with_fixed_base_msm_tables(oracle, fold_tables):
+    """bp_gens_msm_tables: the commitment MSMs and the first round's L / R as fixed-base MSMs over precomputed rows of the
+    generator tables (one bucket set for all Pippenger windows) — proofs byte-identical to the oracle's, alone and together with
+    the first-round fold tables; 0/1 witness vectors (range proofs) overflow a bin and take the ordinary schedule"""
+    import ark_bulletproofs_amd as A
+
+    for cv in (0, 1):
+        e = A.Engine(curve=cv)
+        e.gens_derive(4096)
+        assert e.gens_msm_tables(4096) > 0
+        if fold_tables:
+            e.gens_fold_tables(2048, window_bits=4)
+        for sc, prm, mcap in [(3, [3000, 0], 8), (3, [4096, 0], 8), (0, [2049], 4200), (4, [64, 64, 0], 72)]:
+            ref = oracle.r1cs_prove(cv, sc, prm, SEED, 4096, m_cap=mcap)
+            got = e.prove_scenario(sc, prm, SEED, m_cap=mcap)
+            assert got.proof == ref.proof, (cv, sc, prm)
+        e.gens_msm_tables(0)
+        e.close()
