@@ -49,6 +49,14 @@ struct DevBuf {
         cap = want;
         return BP_OK;
     }
+    // buffers whose kernels rely on "all zero between uses" (and restore it themselves): zeroed once, when (re)allocated
+    int ensure_zeroed(size_t bytes, hipStream_t st) {
+        if (bytes <= cap) return BP_OK;
+        int rc = ensure(bytes);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(p, 0, cap, st));
+        return BP_OK;
+    }
     void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
     template <class T> T* as() { return (T*)p; }
 };
@@ -236,9 +244,11 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     const size_t Bp1 = (size_t)pl.B + 1;
     const u32 ntiles = (pl.B + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
     BPCHK(ctx->canon.ensure(n * 32));
-    BPCHK(ctx->hist.ensure(pl.B * 4));
+    // hist, the bin cursors and the overflow flag are all-zero between MSMs: their last readers (k_msm_scan_apply, k_msm_bin_sort,
+    // the host) restore that, so no memset is enqueued per MSM
+    BPCHK(ctx->hist.ensure_zeroed(pl.B * 4, st));
     BPCHK(ctx->lvl_off.ensure(Bp1 * NL * 4));
-    BPCHK(ctx->totals.ensure((NL + 2) * 4 + (size_t)ntiles * (NL + 1) * 4));
+    BPCHK(ctx->totals.ensure_zeroed((NL + 2) * 4 + (size_t)ntiles * (NL + 1) * 4, st));
     BPCHK(ctx->cursor.ensure(pl.B * 4));
     static const bool force_marginals = getenv("ARKBP_MSM_MARGINALS") != nullptr;   // A/B: the bit-marginal bucket aggregation everywhere
     const bool use_marginals = force_marginals || pl.B < ctx->tune_msm_wsum_min;
@@ -307,18 +317,15 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     u32 b_gen = pl.B;   // buckets below b_gen go through the generic reduction tree; the rest (narrow top window) are special
     auto front_end = [&](bool bins) -> int {
         static const int chl_env = getenv("ARKBP_MSM_CHL") ? atoi(getenv("ARKBP_MSM_CHL")) : 0;
-        chl = bins ? (chl_env >= 3 && chl_env <= 6 ? chl_env : MSM_CHL_BINNED) : MSM_CHL;
+        chl = bins ? (chl_env >= 2 && chl_env <= 6 ? chl_env : MSM_CHL_BINNED) : MSM_CHL;
         static const bool no_special = getenv("ARKBP_MSM_NOSPECIAL") != nullptr;
         b_gen = (bins && bp.top_nb && bp.top_nb <= 16 && !no_special) ? (u32)bp.wb * (u32)pl.NB : pl.B;   // few, huge buckets only: a wider top window fits the generic tree
         const size_t nslots = make_slots(sp, bins ? (int)bp.wb : 0, bins ? (size_t)bp.wb * bp.NBIN * bp.cap : 0);
         if (nslots >= ((size_t)1 << 32)) { g_err = "msm: slot array too large"; return BP_E_ARG; }
         BPCHK(ctx->slots.ensure(nslots * 4));
-        HIPCHK(hipMemsetAsync(ctx->hist.p, 0, pl.B * 4, st));
-        HIPCHK(hipMemsetAsync(d_over, 0, 4, st));
         if (bins) {
-            BPCHK(ctx->bin_cur.ensure((size_t)pl.W * bp.NBIN * 4));
+            BPCHK(ctx->bin_cur.ensure_zeroed((size_t)pl.W * bp.NBIN * 4, st));
             BPCHK(ctx->boff.ensure((size_t)pl.B * 4));
-            HIPCHK(hipMemsetAsync(ctx->bin_cur.p, 0, (size_t)pl.W * bp.NBIN * 4, st));
             const int wg = std::max(1, (int)(12288 / bp.NBIN));   // windows per launch: 48 KiB of LDS counters
             const u32 gp = (u32)((n + (size_t)256 * bp.tpt - 1) / ((size_t)256 * bp.tpt));
             for (int wa = 0; wa < (int)bp.wb; wa += wg) {
@@ -338,6 +345,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
+        if (ctx->h_totals[NL + 1] != 0) HIPCHK(hipMemsetAsync(d_over, 0, 4, st));   // the overflow flag was raised: lower it for the next pass / MSM
         return BP_OK;
     };
     static const bool mtrace = getenv("ARKBP_MSM_TRACE") != nullptr;   // host-side phase times of every MSM on stderr
@@ -520,8 +528,8 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     const size_t Bp1 = (size_t)pl.B + 1;
     const u32 ntiles = (pl.B + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
     const u32 nblk_ws = (u32)((pl.NB + 256 * MSM_SEG - 1) / (256 * MSM_SEG));
-    BPCHK(ctx->canon.ensure(n * 32)); BPCHK(ctx->hist.ensure((size_t)pl.B * 4)); BPCHK(ctx->lvl_off.ensure(Bp1 * NL * 4));
-    BPCHK(ctx->totals.ensure((NL + 2) * 4 + (size_t)ntiles * (NL + 1) * 4)); BPCHK(ctx->bin_cur.ensure((size_t)nbin * 4)); BPCHK(ctx->boff.ensure((size_t)pl.B * 4));
+    BPCHK(ctx->canon.ensure(n * 32)); BPCHK(ctx->hist.ensure_zeroed((size_t)pl.B * 4, st)); BPCHK(ctx->lvl_off.ensure(Bp1 * NL * 4));
+    BPCHK(ctx->totals.ensure_zeroed((NL + 2) * 4 + (size_t)ntiles * (NL + 1) * 4, st)); BPCHK(ctx->bin_cur.ensure_zeroed((size_t)nbin * 4, st)); BPCHK(ctx->boff.ensure((size_t)pl.B * 4));
     BPCHK(ctx->slots.ensure((size_t)nbin * cap * 4)); BPCHK(ctx->Tbuf.ensure(((size_t)nblk_ws + 1) * 96));
     if (!ctx->h_totals) HIPCHK(hipHostMalloc((void**)&ctx->h_totals, 64));
     if (ctx->h_T_cap < 96) { if (ctx->h_T) HIPCHK(hipHostFree(ctx->h_T)); HIPCHK(hipHostMalloc((void**)&ctx->h_T, 4096)); ctx->h_T_cap = 4096; }
@@ -531,8 +539,6 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     u32* d_tiles = d_tot + (NL + 2);
     u32* d_over = d_tot + (NL + 1);
     const int chl = MSM_CHL_BINNED;
-    HIPCHK(hipMemsetAsync(d_over, 0, 4, st));
-    HIPCHK(hipMemsetAsync(ctx->bin_cur.p, 0, (size_t)nbin * 4, st));
     const u32 gp = (u32)((n + (size_t)256 * bp.tpt - 1) / ((size_t)256 * bp.tpt));
     hipLaunchKernelGGL(k_msm_fb_partition<C>, dim3(gp), dim3(256), (size_t)nbin * 4, st, ssegs, ctx->canon.as<u32>(), pl, scalars_mont, bp, tbits, ctx->bin_cur.as<u32>(),
                        ctx->slots.as<u32>(), d_over);
@@ -546,7 +552,11 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     const u32* tot = ctx->h_totals;
-    if (tot[NL + 1] != 0) { total.stop(); return BP_OK; }   // a bin region overflowed (skewed scalars): the ordinary MSM handles those
+    if (tot[NL + 1] != 0) {   // a bin region overflowed (skewed scalars): the ordinary MSM handles those
+        HIPCHK(hipMemsetAsync(d_over, 0, 4, st));
+        total.stop();
+        return BP_OK;
+    }
     result = G::inf();
     done = true;
     if (tot[0] == 0) { total.stop(); return BP_OK; }

@@ -277,7 +277,7 @@ k_msm_bin_partition(ScalSegs scalars, u32* __restrict__ canon, u32* __restrict__
 // grid (NBIN, W).  Binned window: sort the bin region by fine bucket in LDS; write hist and boff for its 2^LB buckets and the
 // entries back as (term << 1) | sign.  Slot window: boff only (hist was counted by k_msm_bin_partition's atomics).
 __global__ void __launch_bounds__(256)
-k_msm_bin_sort(u32* __restrict__ ent, const u32* __restrict__ bin_cur, u32* __restrict__ hist, u32* __restrict__ boff, MsmPlan pl, BinPlan bp,
+k_msm_bin_sort(u32* __restrict__ ent, u32* __restrict__ bin_cur, u32* __restrict__ hist, u32* __restrict__ boff, MsmPlan pl, BinPlan bp,
                SlotPlan sp) {
     extern __shared__ u32 lds[];
     const u32 w = blockIdx.y, bin = blockIdx.x, tid = threadIdx.x;
@@ -293,6 +293,7 @@ k_msm_bin_sort(u32* __restrict__ ent, const u32* __restrict__ bin_cur, u32* __re
     const u32 n = min(bin_cur[w * bp.NBIN + bin], bp.cap);
     for (u32 x = tid; x < NF; x += 256) cnt[x] = 0;
     __syncthreads();
+    if (tid == 0) bin_cur[w * bp.NBIN + bin] = 0;   // consumed (every lane has read it): the cursors are all-zero between MSMs
     const u32 fmask = NF - 1u;
     for (u32 x = tid; x < n; x += 256) {
         const u32 e = ent[region + x];
@@ -445,7 +446,7 @@ __global__ void __launch_bounds__(64) k_msm_scan_top(u32* __restrict__ tile_sums
     totals[k] = run;
     if (k < MSM_NLMAX) lvl_off[(size_t)k * (B + 1) + B] = run;
 }
-__global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl, int chl, u32 b_gen, int spl) {
+__global__ void __launch_bounds__(256) k_msm_scan_apply(u32* __restrict__ hist, const u32* __restrict__ tile_sums, u32* __restrict__ lvl_off, u32 B, int nl, int chl, u32 b_gen, int spl) {
     __shared__ u32 sh[MSM_NLMAX][4];
     const u32 base = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 8;
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -455,6 +456,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const u32* __restrict__ 
     for (u32 j = 0; j < 8; j++) {
         const u32 b = base + j;
         u32 v = b < B ? hist[b] : 0;
+        if (b < B) hist[b] = 0;   // last reader: the histogram is all-zero between MSMs (no memset per MSM)
         cnt[j] = v;
         for (int k = 0; k < nl; k++) { sum[k] += v; v = msm_next_level(v, k, chl, b >= b_gen, spl); }
     }

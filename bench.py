@@ -388,9 +388,6 @@ def run_prove(args, rank, world, local):
     pipe = ProvePipeline(E, engs, args, N)
     if args.warmup:
         pipe.run(100, args.batch * args.warmup, [None] * (args.batch * args.warmup))
-    for e in engs:
-        e.set_profiling(True)
-        e.reset_profiling()
     nproofs = args.batch * args.steps
     flat = [None] * nproofs
     barrier(world)
@@ -405,8 +402,8 @@ def run_prove(args, rank, world, local):
         stages += np.array(tm)
     # kernel durations for the roofline: ONE more proof, alone on the GPU, after the timed region — HIP-event times taken while
     # several streams share the GPU include the other streams' kernels
-    for e in engs:
-        e.reset_profiling()
+    engs[0].set_profiling(True)     # (HIP events only here: the timed pipeline above runs without them)
+    engs[0].reset_profiling()
     iso = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], statement_seed(120, 0))
     iso.precompute()
     iso.prove(engs[0])
