@@ -287,7 +287,10 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
             for (u32 e = i; e < t.n_const; e += N) {   // (lanes share the constant terms; a handful per circuit, or one per gate)
                 const u32 cid = t.const_c[e];
                 const Fe zq = pow_table<F>(ztab, t.const_q[e] + 1);
-                const Fe term = (cid & 0x80000000u) ? zq : (cid & 0x40000000u) ? fe_wred<F>(fe_neg<F, 2>(zq)) : fe_mul<F>(zq, load_fe_dev<F>(coefs + (size_t)cid * 8));
+                Fe term;
+                if (cid & 0x80000000u) term = zq;
+                else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zq));
+                else term = fe_mul<F>(zq, load_fe_dev<F>(coefs + (size_t)cid * 8));
                 wcp = fe_addr<F>(wcp, term);
             }
             if (t.n_const > i) ad = fe_addr<F>(ad, fe_neg<F, 4>(fe_mul<F>(load_fe_dev<F>(cst + 48), wcp)));

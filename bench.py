@@ -209,7 +209,7 @@ def run_msm(args, rank, world, local):
     if acc_n:
         avg_s = acc_ms / acc_n * 1e-3
         res["roofline"] = {"bound": "hbm", "kernel": "k_msm_accum", "achieved": n * 96 / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": n * 96 / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("msm/k_msm_accum<Secq>", n == 1 << 16 and args.curve == 0, "r01_pmc_msm_2p16_summary.json"),
+                           "frac": n * 96 / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("msm/k_msm_accum<Secq>", n == 1 << 16 and args.curve == 0, "r02_pmc_msm_summary.json"),
                            "avg_kernel_ms": acc_ms / acc_n,
                            "msm_all_kernels_ms": tot_ms / max(tot_n, 1)}
         W, c = E.msm_window_count(args.curve, n)
@@ -435,12 +435,14 @@ def run_prove(args, rank, world, local):
         # zorro: 257 x 8 + ~87 x 11 + ~70.
         per_lane = 1950.0 if args.curve == 0 else 3080.0
         modmul = 2.0 * (N - 1) * per_lane
-        res["roofline"] = {"bound": "hbm", "kernel": "IPA G/H fold (k_ipa_fold_glv + k_ipa_fold_finish + k_ipa_fold_ab), all rounds of one proof",
+        res["roofline"] = {"bound": "hbm", "kernel": "IPA G/H fold (k_ipa_fold_tab [round 1] + k_ipa_fold_glv + k_ipa_fold_finish + k_ipa_fold_ab), all rounds of one proof",
                            "achieved": 576.0 * (N - 1) / per_proof_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 576.0 * (N - 1) / per_proof_s / 1e9 / HBM_PEAK_GBS,
                            # HBM bytes of all fold launches of ONE proof (same unit as `achieved`), from the committed PMC passes of this shape
-                           "traffic": pmc_traffic(["prove2p20/k_ipa_fold_glv<Secq>", "prove2p20/k_ipa_fold_finish<Secq>", "prove2p20/k_ipa_fold_ab<Secq>"],
-                                                  args.logn == 20 and args.curve == 0, "r01_pmc_prove_2p20_summary.json", "all_launches"),
+                           # (with the first-round fold tables the group streams 34 table rows per point of round 1: ~2.2 GB per proof,
+                           # 0.3 ms at HBM speed, for ~12 ms of ladder arithmetic saved — deliberate traffic, not re-reads)
+                           "traffic": pmc_traffic(["prove2p20/k_ipa_fold_glv<Secq>", "prove2p20/k_ipa_fold_tab<Secq>", "prove2p20/k_ipa_fold_finish<Secq>", "prove2p20/k_ipa_fold_ab<Secq>"],
+                                                  args.logn == 20 and args.curve == 0 and bool(args.fold_tables), "r02_pmc_prove2p20_summary.json", "all_launches"),
                            "avg_kernel_ms": fold_ms / max(fold_n, 1), "fold_ms_per_proof": fold_ms,
                            "msm_kernels_ms_per_proof": msm_ms, "msm_accum_ms_per_proof": acc_ms,
                            "valu": {"unit": "G modmul/s", "achieved": modmul / per_proof_s / 1e9, "peak": 169.0, "frac": modmul / per_proof_s / 1e9 / 169.0,
@@ -527,7 +529,7 @@ def run_verify(args, rank, world, local):
         nproofs_per_launch = inst.n * args.steps / max(vs_n, 1)  # the batch goes through in blocks of 512 proofs, one k_vfy_batch launch each
         res["roofline"] = {"bound": "hbm", "kernel": "k_vfy_batch (one launch per block of 512 proofs)", "achieved": 160.0 * N * nproofs_per_launch / avg_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * N * nproofs_per_launch / avg_s / 1e9 / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic("verify4096/k_vfy_batch<Secq>", args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512 and not shuffle_k, "r01_pmc_verify_4096_summary.json"),
+                           "traffic": pmc_traffic("verify4096/k_vfy_batch<Secq>", args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512 and not shuffle_k, "r02_pmc_verify4096_summary.json"),
                            "avg_kernel_ms": vs_ms / vs_n, "algorithmic_bytes_per_verify": per_proof_bytes}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         from oracle import pyoracle as O

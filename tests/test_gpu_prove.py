@@ -204,6 +204,10 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
     single = A.Engine(curve=cv)
     single.gens_derive(N)
     refs = [single.prove_scenario(sc, prm, SEED, m_cap=N + 16) for sc, prm in cases]
+    # the ranks share the first-round fold tables and the fixed-base MSM rows too (the cyclic slices index them with a stride;
+    # the fixed-base MSMs step aside in sharded mode): same proofs
+    single.gens_fold_tables(N // 2, window_bits=4)
+    single.gens_msm_tables(N)
     for (sc, prm), ref in zip(cases, refs):
         assert single.verify_scenario(sc, prm, ref.proof, ref.commitments, ref.publics) == 0
     bar = threading.Barrier(world)
