@@ -368,7 +368,13 @@ def run_prove(args, rank, world, local):
     if args.fold_tables:
         # fixed-base tables of the generators for the first fold round (one-time setup like the derivation above; HBM-resident)
         t0 = time.perf_counter()
-        wbits, nbytes = engs[0].gens_fold_tables(N // 2, window_bits=args.fold_table_bits)
+        # HBM budget: what is free now, minus the fixed-base MSM rows (65 x 64 B per generator, two vectors), the per-proof
+        # workspaces of the proofs in flight (~3 KB per constraint each, MSM sort and tree buffers included) and some slack
+        import torch
+
+        free_b, _ = torch.cuda.mem_get_info(local)
+        budget = int(free_b) - (2 * 65 * 64 * N if args.msm_tables else 0) - P * 3000 * N - (8 << 30)
+        wbits, nbytes = engs[0].gens_fold_tables(N // 2, window_bits=args.fold_table_bits, budget_bytes=max(budget, 1 << 30))
         tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0}
     msm_tab_info = None
     if args.msm_tables and not window_sharded:
