@@ -129,6 +129,8 @@ struct bp_ctx {
     hipEvent_t vstage_ev[2] = {nullptr, nullptr};
     void* h_upload = nullptr;                 // pinned slab for the prover's witness uploads (r1cs_host.inc upload_scalars_pinned)
     size_t h_upload_cap = 0;
+    void* h_csc = nullptr;                    // pinned staging of the prover's constraint index
+    size_t h_csc_cap = 0;
     void* h_dec = nullptr;                    // pinned: x words, points, flags, ok of a batch's compressed points
     size_t h_dec_cap = 0;
     hipStream_t aux_stream = nullptr;         // point decompression runs beside the main stream
@@ -1685,6 +1687,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); if (c->dec_ev[i]) (void)hipEventDestroy(c->dec_ev[i]); }
     for (int i = 0; i < 2; i++) if (c->h_vaux[i]) (void)hipHostFree(c->h_vaux[i]);
     if (c->h_upload) (void)hipHostFree(c->h_upload);
+    if (c->h_csc) (void)hipHostFree(c->h_csc);
     if (c->h_dec) (void)hipHostFree(c->h_dec);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     (void)hipStreamDestroy(c->stream);
