@@ -598,7 +598,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="independent proofs per step per GPU (prove workload)")
     ap.add_argument("--host-threads", type=int, default=5, help="host threads running the TranscriptRng head of prove()")
     ap.add_argument("--build-threads", type=int, default=8, help="host threads constructing statements (Prover::new + commit + gadget)")
-    ap.add_argument("--inflight", type=int, default=12, help="independent proofs in flight per GPU (prove workload)")
+    ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--window", type=int, default=64, help="statements alive at once in the prove pipeline (built, waiting for or in the TranscriptRng stage, "
                     "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s")
     ap.add_argument("--fold-tables", type=int, default=1, help="prove workload: fixed-base tables of the generators for the first fold round (0 = off)")
