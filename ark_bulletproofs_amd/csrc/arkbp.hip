@@ -148,6 +148,7 @@ struct bp_ctx {
     bp_allgather_cb gather_cb = nullptr;   // optional: lets the prover partition the IPA index-cyclically (bp_ctx_set_shard_allgather)
     void* gather_user = nullptr;
     size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
+    size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
     DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
     // fixed-base MSM rows of the generators (bp_gens_msm_tables): row r of a table = 2^(4r) * base, r < FB_ROWS, layout [r][i]
     DevBuf fb_G, fb_H, fb_pc;
@@ -477,7 +478,9 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     typedef host::Grp<C> G;
     done = false;
     static const bool off = getenv("ARKBP_MSM_NOFIXED") != nullptr;   // A/B switch
-    if (off || !ctx->fb_cap || ctx->shard_world > 1 || n < 4096 || n >= ((size_t)1 << 24) || nruns > MSM_MAXSEG) return BP_OK;
+    // pays from ~2^20 terms (2^21: all kernels 5.6 -> 4.5 ms; at 2^19 and below the single latency-bound aggregation pass costs more
+    // than the saved additions: tools/exp_msm_gens.py)
+    if (off || !ctx->fb_cap || ctx->shard_world > 1 || n < std::max<size_t>(ctx->tune_msm_fixed_min, 4096) || n >= ((size_t)1 << 24) || nruns > MSM_MAXSEG) return BP_OK;
     BaseSegs segs; memset(&segs, 0, sizeof segs);
     u32 at = 0;
     for (int k = 0; k < nruns; k++) {
@@ -599,6 +602,21 @@ template <class C> static int msm_gens_entry(bp_ctx* c, int use_G, int use_H, si
     if (total == 0) { memset(out_xy, 0, 64); return BP_OK; }
     BPCHK(c->io_scal.ensure(total * 32));
     HIPCHK(hipMemcpyAsync(c->io_scal.p, scalars, total * 32, hipMemcpyHostToDevice, c->stream));
+    if (!n_extra && (ng || nh)) {   // only generator-table bases: the fixed-base schedule when the rows are installed (bp_gens_msm_tables)
+        FbRun runs[2]; int nr = 0;
+        if (ng) runs[nr++] = FbRun{0, off, ng};
+        if (nh) runs[nr++] = FbRun{1, off, nh};
+        ScalSegs ss; memset(&ss, 0, sizeof ss);
+        ss.nseg = 1; ss.ptr[0] = c->io_scal.as<u32>(); ss.start[0] = 0; ss.start[1] = (u32)total;
+        J4 r; bool done = false;
+        BPCHK(msm_fixed_run<C>(c, runs, nr, ss, total, canonical ? 0 : 1, r, done));
+        if (done) {
+            A4 a = host::Grp<C>::to_aff(r);
+            memcpy(out_xy, a.x.v, 32); memcpy(out_xy + 4, a.y.v, 32);
+            if (c->profiling) collect_timers(c);
+            return BP_OK;
+        }
+    }
     if (n_extra) {
         BPCHK(c->io_pts.ensure(n_extra * 64));
         HIPCHK(hipMemcpyAsync(c->io_pts.p, extra_xy, n_extra * 64, hipMemcpyHostToDevice, c->stream));
@@ -1707,6 +1725,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
     if (!c) return BP_E_ARG;
     switch (knob) {
         case BP_TUNE_CYCLIC_MIN: c->tune_cyclic_min = (size_t)value; return BP_OK;
+        case BP_TUNE_MSM_FIXED_MIN: c->tune_msm_fixed_min = (size_t)value; return BP_OK;
         case BP_TUNE_FOLD_BATCH_MIN: c->tune_fold_batch_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_BIN_MIN: c->tune_msm_bin_min = (size_t)value; return BP_OK;
         case BP_TUNE_IPA_FREEZE_LEN: c->tune_ipa_freeze_len = (size_t)value; return BP_OK;

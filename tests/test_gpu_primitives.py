@@ -326,3 +326,24 @@ def test_reference_held_constants_on_gpu(eng, oracle):
         prod = e.debug_field_op(fq, 0, A, B)
         s = e.debug_field_op(fq, 1, e.debug_field_op(fq, 1, prod[0:1], prod[1:2]), e.debug_field_op(fq, 1, prod[2:3], prod[3:4]))
         assert (s[0] == O.fe_from_int(fq, 40)).all()
+
+
+def test_msm_gens_fixed_base_rows_match_ordinary_schedule(eng, oracle):
+    """bp_msm_gens over the resident tables through the fixed-base rows (bp_gens_msm_tables) and through the ordinary schedule:
+    same point; against the oracle's msm at 2 x 3000 terms; skewed scalars (0/1) fall back and still agree"""
+    O = oracle
+    cv = eng.curve
+    n = 3000
+    eng.gens_derive(4096)
+    Go, Ho = O.bp_gens(cv, n)
+    fr = O.fid(cv, True)
+    sc = O.fe_rand(fr, bytes([21]) * 32, 2 * n)
+    want = O.msm(cv, np.concatenate([Go, Ho]), sc)
+    assert (eng.msm_gens(n, sc) == want).all()
+    eng.gens_msm_tables(4096)
+    eng.set_tuning(5, 4096)
+    assert (eng.msm_gens(n, sc) == want).all()
+    assert (eng.msm_gens(n, sc[:n], use_H=False) == O.msm(cv, Go, sc[:n])).all()
+    bits = np.array([O.fe_from_int(fr, (i * 7) & 1) for i in range(2 * n)])
+    assert (eng.msm_gens(n, bits) == O.msm(cv, np.concatenate([Go, Ho]), bits)).all()
+    eng.gens_msm_tables(0)

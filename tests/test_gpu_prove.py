@@ -208,6 +208,7 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
     # the fixed-base MSMs step aside in sharded mode): same proofs
     single.gens_fold_tables(N // 2, window_bits=4)
     single.gens_msm_tables(N)
+    single.set_tuning(5, 4096)
     for (sc, prm), ref in zip(cases, refs):
         assert single.verify_scenario(sc, prm, ref.proof, ref.commitments, ref.publics) == 0
     bar = threading.Barrier(world)
@@ -294,6 +295,7 @@ def test_prove_with_fixed_base_msm_tables(oracle, fold_tables):
         e = A.Engine(curve=cv)
         e.gens_derive(4096)
         assert e.gens_msm_tables(4096) > 0
+        e.set_tuning(5, 4096)      # BP_TUNE_MSM_FIXED_MIN: take the fixed-base schedule at these sizes
         if fold_tables:
             e.gens_fold_tables(2048, window_bits=4)
         for sc, prm, mcap in [(3, [3000, 0], 8), (3, [4096, 0], 8), (0, [2049], 4200), (4, [64, 64, 0], 72)]:
