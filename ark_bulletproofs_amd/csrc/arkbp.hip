@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/arkbp.h"
 #include <atomic>
@@ -127,6 +128,9 @@ struct bp_ctx {
     void* h_vstage[2] = {nullptr, nullptr};   // pinned staging halves of the batch-verify pipeline
     size_t h_vstage_cap[2] = {0, 0};
     hipEvent_t vstage_ev[2] = {nullptr, nullptr};
+    hipEvent_t vtail_ev[2] = {nullptr, nullptr};   // the tails of a block go up on aux_stream
+    std::unique_ptr<host::HostPool> pool;     // host threads of this ctx's data-parallel loops (created on first use)
+    hipEvent_t sync_ev = nullptr;             // blocking-sync event of ctx_stream_wait
     void* h_upload = nullptr;                 // pinned slab for the prover's witness uploads (r1cs_host.inc upload_scalars_pinned)
     size_t h_upload_cap = 0;
     void* h_csc = nullptr;                    // pinned staging of the prover's constraint index
@@ -168,6 +172,18 @@ static int get_event(bp_ctx* c, hipEvent_t* e) {
     if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); return BP_OK; }
     HIPCHK(hipEventCreate(e));
     return BP_OK;
+}
+// Waits for the ctx's stream.  hipStreamSynchronize spins on the host; with a dozen proofs in flight that is a dozen cores doing
+// nothing — on a box whose CPU time is rationed (the GPU boxes here grant 16 CPUs per GPU through a cgroup quota) the spinning
+// starves the threads that have real work (TranscriptRng, statement construction, transcript replays).  Waiting on an event created
+// with hipEventBlockingSync sleeps instead.  ARKBP_SYNC=spin restores the spinning wait (A/B).
+static hipError_t ctx_stream_wait(bp_ctx* c) {
+    static const bool spin = getenv("ARKBP_SYNC") && !strcmp(getenv("ARKBP_SYNC"), "spin");
+    if (spin) return hipStreamSynchronize(c->stream);
+    if (!c->sync_ev) { hipError_t e = hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming); if (e != hipSuccess) return e; }
+    hipError_t e = hipEventRecord(c->sync_ev, c->stream);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(c->sync_ev);
 }
 struct ScopedK {  // records start/stop events around a region when profiling is on
     bp_ctx* c; int which; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
@@ -346,7 +362,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
         hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl, chl, b_gen, spl);
         HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(ctx_stream_wait(ctx));
         HIPCHK(hipGetLastError());
         if (ctx->h_totals[NL + 1] != 0) HIPCHK(hipMemsetAsync(d_over, 0, 4, st));   // the overflow flag was raised: lower it for the next pass / MSM
         return BP_OK;
@@ -410,7 +426,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tbytes, hipMemcpyDeviceToHost, st));
     total.stop();
     const double t_m2 = mtrace ? tnow() : 0;
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(ctx_stream_wait(ctx));
     HIPCHK(hipGetLastError());
     const double t_m3 = mtrace ? tnow() : 0;
     J4 acc = G::inf();
@@ -465,7 +481,7 @@ template <class C> static int fb_tables_build(bp_ctx* ctx, size_t cap) {
     BPCHK(build(ctx->d_G.as<u32>(), ctx->fb_G.as<u32>(), cap, cap));
     BPCHK(build(ctx->d_H.as<u32>(), ctx->fb_H.as<u32>(), cap, cap));
     BPCHK(build(ctx->d_pc.as<u32>(), ctx->fb_pc.as<u32>(), 2, 2));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(ctx_stream_wait(ctx));
     tmp.release(); pref.release(); outb.release();
     ctx->fb_cap = cap;
     return BP_OK;
@@ -554,7 +570,7 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, lvl, pl.B, nl, chl, pl.B, 1);
     HIPCHK(hipMemcpyAsync(ctx->h_totals, d_tot, (NL + 2) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(ctx_stream_wait(ctx));
     HIPCHK(hipGetLastError());
     const u32* tot = ctx->h_totals;
     if (tot[NL + 1] != 0) {   // a bin region overflowed (skewed scalars): the ordinary MSM handles those
@@ -587,7 +603,7 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     hipLaunchKernelGGL(k_msm_sum_partials<C>, dim3(1), dim3(256), 0, st, ctx->Tbuf.as<u32>(), nblk_ws, ctx->Tbuf.as<u32>() + (size_t)nblk_ws * 24);
     HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.as<u32>() + (size_t)nblk_ws * 24, 96, hipMemcpyDeviceToHost, st));
     total.stop();
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(ctx_stream_wait(ctx));
     HIPCHK(hipGetLastError());
     const u64* T = (const u64*)ctx->h_T;
     J4 pnt; memcpy(pnt.X.v, T, 32); memcpy(pnt.Y.v, T + 4, 32); memcpy(pnt.Z.v, T + 8, 32);
@@ -858,7 +874,7 @@ template <class C> static int ftab_build(bp_ctx* ctx, size_t n, int w, size_t bu
         }
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(ctx_stream_wait(ctx));
     tmp.release(); pref.release(); state.release();
     ctx->ftab_n = n; ctx->ftab_w = w; ctx->ftab_nwin = nwin;
     return BP_OK;
@@ -1078,7 +1094,7 @@ template <class C> static int ipa_finish_dev(bp_ctx* ctx, IpaState& s, uint64_t 
     hipLaunchKernelGGL(k_scalars_export<typename C::Fr>, dim3(1), dim3(64), 0, st, s.d_b, ctx->io_out.as<u32>() + 8, 1u);
     uint64_t ab[8];
     HIPCHK(hipMemcpyAsync(ab, ctx->io_out.p, 64, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(ctx_stream_wait(ctx));
     HIPCHK(hipGetLastError());
     memcpy(a_out, ab, 32); memcpy(b_out, ab + 4, 32);
     if (ctx->profiling) collect_timers(ctx);
@@ -1187,7 +1203,7 @@ static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const
         hipLaunchKernelGGL(k_points_dev_to_ark<C>, dim3(g2), dim3(256), 0, st, s.d_H, o + m * 32, (u32)m);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(send.data(), o, per, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(ctx_stream_wait(ctx));
     }
     { const int rc = ctx->gather_cb(ctx->gather_user, send.data(), per, recv.data()); if (rc) { g_err = "ipa: the all-gather callback failed"; return rc < 0 ? rc : BP_E_ARG; } }
     std::vector<F4> ga(S_glob), gbv(S_glob);
@@ -1220,7 +1236,7 @@ static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const
     hipLaunchKernelGGL(k_ipa_freeze_init<C>, dim3((u32)((S_glob + 255) / 256)), dim3(256), 0, st, t.d_cG, t.d_cH, (u32)S_glob, s.pending ? (s.h_geo ? 2 : 1) : 0,
                        words_of<S>(s.gamma_G), words_of<S>(kH), d_rho_pow);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));   // ga .. gH are locals
+    HIPCHK(ctx_stream_wait(ctx));   // ga .. gH are locals
     t.frozen = true; t.n0 = S_glob;
     while (t.n != 1) {
         uint64_t Lw[8], Rw[8], uw[4];
@@ -1265,7 +1281,7 @@ static int ipa_upload_host(bp_ctx* ctx, const uint64_t* Q, const uint64_t* Gf, c
     DevBuf* sc[] = {&ctx->ipa_a, &ctx->ipa_b, &ctx->ipa_Gf, &ctx->ipa_Hf};
     for (auto s : sc) hipLaunchKernelGGL(k_scalars_import<Fr>, dim3(gb), dim3(256), 0, st, s->as<u32>(), s->as<u32>(), (u32)n);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));   // the host buffers are the caller's: done with them before returning
+    HIPCHK(ctx_stream_wait(ctx));   // the host buffers are the caller's: done with them before returning
     return BP_OK;
 }
 template <class C>
@@ -1307,7 +1323,7 @@ static int ipa_export_host(bp_ctx* ctx, uint64_t* a, uint64_t* b, uint64_t* G_xy
     HIPCHK(hipMemcpyAsync(H_xy, o + n * 16, n * 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(a, o + n * 32, n * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(b, o + n * 40, n * 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(ctx_stream_wait(ctx));
     memcpy(gG, s.gamma_G.v, 32); memcpy(gH, s.gamma_H.v, 32);
     *n_cur = n;
     return BP_OK;
@@ -1511,7 +1527,7 @@ template <class C> static int dbg_exp_iter(bp_ctx* ctx, const uint64_t* x, size_
     hipLaunchKernelGGL(k_dbg_exp_iter<typename C::Fr>, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->r_ypow.as<u32>(), (u32)n, ctx->io_out.as<u32>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, ctx->io_out.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx_stream_wait(ctx));
     return BP_OK;
 }
 // <a, b> over the scalar field with the kernels InnerProductProof::create uses for c_L = <a_L, b_R> (k_ipa_scalars +
@@ -1535,7 +1551,7 @@ template <class C> static int dbg_inner_product(bp_ctx* ctx, const uint64_t* a, 
     HIPCHK(hipGetLastError());
     uint64_t canon[4];
     HIPCHK(hipMemcpyAsync(canon, sL + 2 * n * 8, 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(ctx_stream_wait(ctx));
     F4 r = S::from_canon(canon);
     memcpy(out, r.v, 32);
     return BP_OK;
@@ -1694,6 +1710,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
@@ -1702,7 +1719,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
-    for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); if (c->dec_ev[i]) (void)hipEventDestroy(c->dec_ev[i]); }
+    for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); if (c->vtail_ev[i]) (void)hipEventDestroy(c->vtail_ev[i]); if (c->dec_ev[i]) (void)hipEventDestroy(c->dec_ev[i]); }
     for (int i = 0; i < 2; i++) if (c->h_vaux[i]) (void)hipHostFree(c->h_vaux[i]);
     if (c->h_upload) (void)hipHostFree(c->h_upload);
     if (c->h_csc) (void)hipHostFree(c->h_csc);
@@ -1735,7 +1752,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
 }
 int bp_ctx_sync(bp_ctx* c) {
     if (!c) return BP_E_ARG;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(ctx_stream_wait(c));
     return BP_OK;
 }
 
@@ -1747,20 +1764,20 @@ int bp_dev_alloc(bp_ctx* c, size_t bytes, void** dptr) {
 }
 int bp_dev_free(bp_ctx* c, void* dptr) {
     if (!c) return BP_E_ARG;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(ctx_stream_wait(c));
     HIPCHK(hipFree(dptr));
     return BP_OK;
 }
 int bp_dev_upload(bp_ctx* c, void* dptr, const void* hostp, size_t bytes) {
     if (!c || (!dptr && bytes) || (!hostp && bytes)) return BP_E_ARG;
     HIPCHK(hipMemcpyAsync(dptr, hostp, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(ctx_stream_wait(c));
     return BP_OK;
 }
 int bp_dev_download(bp_ctx* c, void* hostp, const void* dptr, size_t bytes) {
     if (!c || (!dptr && bytes) || (!hostp && bytes)) return BP_E_ARG;
     HIPCHK(hipMemcpyAsync(hostp, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(ctx_stream_wait(c));
     return BP_OK;
 }
 int bp_points_import(bp_ctx* c, const void* d_in, void* d_out, size_t n) {
@@ -1907,7 +1924,7 @@ int bp_gens_download(bp_ctx* c, uint64_t* G_xy, uint64_t* H_xy, size_t n) {
     for (int k = 0; k < 2; k++) {
         BPCHK(bp_points_export(c, k ? c->d_H.p : c->d_G.p, c->io_pts.p, n));
         HIPCHK(hipMemcpyAsync(k ? H_xy : G_xy, c->io_pts.p, n * 64, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(ctx_stream_wait(c));
     }
     return BP_OK;
 }
@@ -2304,7 +2321,7 @@ int bp_debug_field_op(bp_ctx* c, int field, int op, const uint64_t* a, const uin
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, po, n * 32, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(ctx_stream_wait(c));
     return BP_OK;
 }
 int bp_debug_point_op(bp_ctx* c, int op, const uint64_t* p, const uint64_t* q, const uint64_t* k, uint64_t* out, size_t n) {
@@ -2321,7 +2338,7 @@ int bp_debug_point_op(bp_ctx* c, int op, const uint64_t* p, const uint64_t* q, c
     else hipLaunchKernelGGL(k_dbg_point<Zorro>, dim3(gb), dim3(64), 0, c->stream, op, dp, dq, c->io_scal.as<u32>(), c->io_out.as<u32>(), (u32)n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, c->io_out.p, n * 64, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(ctx_stream_wait(c));
     return BP_OK;
 }
 

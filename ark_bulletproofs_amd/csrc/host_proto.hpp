@@ -12,8 +12,11 @@
 #if defined(__linux__)
 #include <sys/mman.h>
 #endif
+#include <atomic>
+#include <condition_variable>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -64,6 +67,58 @@ static inline unsigned host_pool_threads() {
     if (const char* e = getenv("ARKBP_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) n = (unsigned)v; }
     return n;
 }
+
+// A persistent pool for the library's data-parallel host loops (the per-instance transcript replays of batch verification run
+// once per block of 512 instances: spawning 32 threads per block cost ~0.8 ms of the ~2 ms a block takes, and thread creation
+// maps stacks under the process's mmap lock, so concurrent batches serialised on it).  run(lo, hi, fn): fn(k) for every k in
+// [lo, hi), dynamically scheduled over the workers and the calling thread; returns when all are done.  One job at a time per pool.
+class HostPool {
+public:
+    explicit HostPool(unsigned workers) {
+        for (unsigned t = 0; t < workers; t++) th_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(m_); quit_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void run(size_t lo, size_t hi, const std::function<void(size_t)>& fn) {
+        if (hi <= lo) return;
+        if (hi - lo == 1 || th_.empty()) { for (size_t k = lo; k < hi; k++) fn(k); return; }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn; next_.store(lo); hi_ = hi; pending_ = th_.size(); gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void work() { for (;;) { const size_t k = next_.fetch_add(1); if (k >= hi_) break; (*fn_)(k); } }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (quit_) return;
+            }
+            work();
+            { std::lock_guard<std::mutex> g(m_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    std::atomic<size_t> next_{0};
+    size_t hi_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool quit_ = false;
+};
 
 // ---- ChaCha20Rng (rand_chacha 0.3: 64-bit counter, stream 0, sequential u32 word stream) ------------------
 struct ChaChaRng {

@@ -503,22 +503,52 @@ def run_verify(args, rank, world, local):
     inst_list = [distinct[i % len(distinct)] for i in range(lo, hi)]
     inst = E.pack_instances(inst_list)   # the C ABI's flat arrays, marshalled once (a host in the reference's language owns them already)
     seed = bytes([5]) * 32
+    # `--verify-inflight` batches in flight per GPU (like the prover's proofs in flight): each on its own ctx / stream with its own
+    # host pool, sharing the resident generator tables.  One batch alone leaves the GPU idle while the host parses and replays the
+    # first block and the host idle during the drain and the final MSM; a second batch fills those.
+    nfl = max(1, args.verify_inflight) if world == 1 else 1      # (sharded runs exchange a point per step: one batch at a time)
+    engs = [eng]
+    for _ in range(nfl - 1):
+        e2 = A.Engine(curve=args.curve, device=local)
+        e2.share_gens_from(eng)
+        engs.append(e2)
     for _ in range(args.warmup):
-        eng.batch_verify(inst, seed, alpha_skip=lo)
+        for e in engs:
+            e.batch_verify(inst, seed, alpha_skip=lo)
     eng.set_profiling(True)
     eng.reset_profiling()
     barrier(world)
     t0 = time.perf_counter()
     tms = np.zeros(5)
     ok = True
-    for _ in range(args.steps):
-        rc, tm, pt = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
-        parts = P.allgather_points(pt, device=COLL_DEVICE if world > 1 else None)
-        ok = ok and rc == 0 and not E.host_points_sum(args.curve, parts).any()
-        tms += np.array(tm)
+    if nfl == 1:
+        for _ in range(args.steps):
+            rc, tm, pt = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
+            parts = P.allgather_points(pt, device=COLL_DEVICE if world > 1 else None)
+            ok = ok and rc == 0 and not E.host_points_sum(args.curve, parts).any()
+            tms += np.array(tm)
+    else:
+        nxt, lock, oks, tml = [0], threading.Lock(), [], []
+
+        def worker(e):
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= args.steps:
+                    return
+                rc, tm, pt = e.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
+                oks.append(rc == 0 and not pt.any())
+                tml.append(tm)
+
+        run_threads([(worker, (e,)) for e in engs])
+        ok = all(oks) and len(oks) == args.steps
+        tms = np.sum(np.array(tml), axis=0)
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     assert ok, "batch verification of valid proofs failed"
+    for e in engs[1:]:
+        e.close()
     k = int(np.log2(N))
     m_commit = 2 * shuffle_k if shuffle_k else nval
     per_proof_bytes = 352 * N + 96 * (13 + m_commit + 2 * k)
@@ -532,6 +562,7 @@ def run_verify(args, rank, world, local):
                                ("cfg4: batch_verify of %d R1CS proofs per GPU, 2^14 constraints each (256 x 64-bit range proofs, m=256), %s"
                                 % (args.proofs, CURVES[args.curve])),
                    "proofs_per_gpu": args.proofs, "distinct_proofs": len(distinct), "constraints_per_proof": N, "parallelism": "proof-sharded x%d" % world,
+                   "batches_in_flight": nfl,
                    "stage_ms_per_step": {"whole_call": tms[0] / args.steps * 1e3, "host_replay_overlapped_with_gpu": tms[1] / args.steps * 1e3,
                                          "gpu_drain_and_tail_scaling": tms[2] / args.steps * 1e3, "final_msm": tms[3] / args.steps * 1e3,
                                          "decode": tms[4] / args.steps * 1e3}},
@@ -600,6 +631,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
+    ap.add_argument("--verify-inflight", type=int, default=2, help="verify workload: batch_verify calls in flight per GPU (own ctx each)")
     ap.add_argument("--shuffle-k", type=int, default=0, help="verify workload: batches of k-shuffle proofs (the reference's two-phase benchmark circuit) instead of cfg4's range proofs")
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
