@@ -113,6 +113,7 @@ struct bp_ctx {
     std::vector<hipEvent_t> event_pool;
     // MSM workspaces
     DevBuf canon, hist, lvl_off, totals, cursor, entries, slots, bin_cur, boff, lvA, lvB, Tbuf, io_pts, io_scal, io_out;
+    DevBuf fs_bcnt, fs_loff, fs_binch, fs_sums;   // fixed-shape MSM pipeline (msm.cuh 7)
     // IPA workspaces (resident layouts)
     DevBuf ipa_G, ipa_H, ipa_a, ipa_b, ipa_Gf, ipa_Hf, ipa_sL, ipa_sR, ipa_part, ipa_Q, ipa_jac, ipa_pref, ipa_cG, ipa_cH;
     // generator tables (BulletproofGens party 0, PedersenGens), resident layout
@@ -368,6 +369,89 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         return BP_OK;
     };
     static const bool mtrace = getenv("ARKBP_MSM_TRACE") != nullptr;   // host-side phase times of every MSM on stderr
+    // ---- the fixed-shape pipeline (msm.cuh 7): no host wait before the last kernel; falls through to the general path on overflow ----
+    static const bool no_fs = getenv("ARKBP_MSM_NOFS") != nullptr;
+    if (binned && use_marginals && !no_fs && (bp.wb == (u32)pl.W || bp.top_nb > 0) && (size_t)bp.wb * bp.NBIN + 1 <= MSM_FS_MAXBINS && !segs.fixed_c4) {
+        const auto tfs = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_f0 = mtrace ? tfs() : 0;
+        static const int chl_fs_env = getenv("ARKBP_MSM_FS_CHL") ? atoi(getenv("ARKBP_MSM_FS_CHL")) : 0;   // experiments
+        const int chl_fs = chl_fs_env >= 2 && chl_fs_env <= 6 ? chl_fs_env : MSM_CHL_BINNED;
+        FsPlan fp; memset(&fp, 0, sizeof fp);
+        fp.has_top = bp.wb < (u32)pl.W ? 1u : 0u;
+        fp.nbins = bp.wb * bp.NBIN + fp.has_top;
+        if (fp.has_top) { u32 t = bp.top_nb; while (t) { fp.top_bits++; t >>= 1; } }
+        const size_t nwin = (size_t)(pl.w_hi - pl.w_lo);
+        const size_t maxch = ((n * nwin) >> chl_fs) + std::min<size_t>(n * nwin, nwin * (size_t)pl.NB) + 64;
+        fp.max_chunks = (u32)maxch;
+        const size_t nslots = make_slots(sp, (int)bp.wb, (size_t)bp.wb * bp.NBIN * bp.cap);
+        const size_t tc = (size_t)bp.wb * pl.c + (size_t)fp.top_bits * MSM_TOP_PARTS;
+        const size_t tb = tc * 96 + 64;
+        if (nslots < ((size_t)1 << 32) && maxch < ((size_t)1 << 31)) {
+            BPCHK(ctx->slots.ensure(nslots * 4));
+            BPCHK(ctx->bin_cur.ensure_zeroed((size_t)pl.W * bp.NBIN * 4, st));
+            BPCHK(ctx->boff.ensure((size_t)pl.B * 4));
+            BPCHK(ctx->fs_bcnt.ensure((size_t)pl.B * 4));
+            BPCHK(ctx->fs_loff.ensure((size_t)pl.B * 4));
+            BPCHK(ctx->fs_binch.ensure((MSM_FS_MAXBINS + 1) * 4));
+            BPCHK(ctx->fs_sums.ensure((size_t)bp.wb * pl.NB * 96));
+            BPCHK(ctx->lvA.ensure(maxch * 96));
+            BPCHK(ctx->Tbuf.ensure(tb));
+            if (ctx->h_T_cap < tb) {
+                if (ctx->h_T) HIPCHK(hipHostFree(ctx->h_T));
+                HIPCHK(hipHostMalloc((void**)&ctx->h_T, tb + 4096));
+                ctx->h_T_cap = tb + 4096;
+            }
+            ScopedK total(ctx, BP_K_MSM_TOTAL);
+            u32* d_over = ctx->totals.as<u32>() + (MSM_NLMAX + 1);
+            u32* d_info = ctx->Tbuf.as<u32>() + tc * 24;
+            const int wg = std::max(1, (int)(12288 / bp.NBIN));
+            const u32 gp = (u32)((n + (size_t)256 * bp.tpt - 1) / ((size_t)256 * bp.tpt));
+            for (int wa = 0; wa < (int)bp.wb; wa += wg) {
+                const int we = std::min<int>((int)bp.wb, wa + wg);
+                hipLaunchKernelGGL(k_msm_bin_partition<C>, dim3(gp), dim3(256), ((size_t)(we - wa) * bp.NBIN + (wa == 0 ? bp.top_nb : 0)) * 4, st, d_scalars, ctx->canon.as<u32>(),
+                                   ctx->hist.as<u32>(), pl, scalars_mont, bp, sp, ctx->bin_cur.as<u32>(), ctx->slots.as<u32>(), d_over, wa, we, wa == 0 ? 1 : 0);
+            }
+            hipLaunchKernelGGL(k_msm_bin_sort_fs, dim3(bp.NBIN, bp.wb + fp.has_top), dim3(256), (((size_t)1 << bp.LB) + 8 + bp.cap) * 4, st, ctx->slots.as<u32>(),
+                               ctx->bin_cur.as<u32>(), ctx->hist.as<u32>(), ctx->boff.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(), ctx->fs_binch.as<u32>(),
+                               d_over, pl, bp, sp, chl_fs);
+            {
+                ScopedK acc(ctx, BP_K_MSM_ACCUM);
+                hipLaunchKernelGGL(k_msm_accum_fs<C>, dim3((u32)((maxch + 255) / 256)), dim3(256), 0, st, segs, ctx->slots.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+                                   ctx->boff.as<u32>(), ctx->fs_binch.as<u32>(), ctx->lvA.as<u32>(), pl, bp, fp, chl_fs, d_info);
+            }
+            hipLaunchKernelGGL(k_msm_reduce_fs<C>, dim3((u32)(((size_t)bp.wb * pl.NB * 4 + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+                               ctx->fs_binch.as<u32>(), ctx->fs_sums.as<u32>(), pl, bp, fp, chl_fs);
+            hipLaunchKernelGGL(k_msm_marginals_fs<C>, dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+                               ctx->Tbuf.as<u32>(), pl, bp, fp, chl_fs, d_info, d_over);
+            HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tb, hipMemcpyDeviceToHost, st));
+            total.stop();
+            const double t_f1 = mtrace ? tfs() : 0;
+            HIPCHK(ctx_stream_wait(ctx));
+            HIPCHK(hipGetLastError());
+            const double t_f2 = mtrace ? tfs() : 0;
+            const u32* info = (const u32*)((const uint8_t*)ctx->h_T + tc * 96);
+            if (info[2] == 0) {
+                J4 acc = G::inf();
+                const u64* T = (const u64*)ctx->h_T;
+                auto add_T = [&](size_t idx) {
+                    const u64* t = T + idx * 12;
+                    J4 p; memcpy(p.X.v, t, 32); memcpy(p.Y.v, t + 4, 32); memcpy(p.Z.v, t + 8, 32);
+                    if (!p.Z.is_zero()) acc = G::add(acc, p);
+                };
+                const int ngen = (int)bp.wb * pl.c;
+                for (int j = ngen + (int)fp.top_bits - 1; j >= 0; j--) {
+                    acc = G::dbl(acc);
+                    if (j >= ngen) { for (u32 q = 0; q < MSM_TOP_PARTS; q++) add_T((size_t)ngen + (size_t)(j - ngen) * MSM_TOP_PARTS + q); }
+                    else add_T((size_t)j);
+                }
+                result = acc;
+                if (mtrace) fprintf(stderr, "[msm-fs] n=%zu c=%d W=%d bins=%u chunks=%u/%u  enqueue %.1f us  wait %.1f us  host tail %.1f us\n", n, pl.c, pl.W, fp.nbins, info[0],
+                                    fp.max_chunks, (t_f1 - t_f0) * 1e6, (t_f2 - t_f1) * 1e6, (tfs() - t_f2) * 1e6);
+                return finish_sharded(result);
+            }
+            if (mtrace) fprintf(stderr, "[msm-fs] n=%zu: overflow, the general path takes over\n", n);
+        }
+    }
     const auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_m0 = mtrace ? tnow() : 0;
     BPCHK(front_end(binned));
@@ -1714,7 +1798,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
-                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->cyc_a, &c->cyc_b, &c->cyc_Gf, &c->cyc_Hf, &c->ftab_G, &c->ftab_H, &c->fb_G, &c->fb_H, &c->fb_pc, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab};
+                      &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->cyc_a, &c->cyc_b, &c->cyc_Gf, &c->cyc_Hf, &c->ftab_G, &c->ftab_H, &c->fb_G, &c->fb_H, &c->fb_pc, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab, &c->fs_bcnt, &c->fs_loff, &c->fs_binch, &c->fs_sums};
     c->templates.clear();
     for (auto b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);

@@ -58,24 +58,28 @@ template <class P> struct Fld {
     }
     static inline F4 neg(const F4& a) { return a.is_zero() ? a : sub(zero(), a); }
     static inline F4 dbl(const F4& a) { return add(a, a); }
-    // separated operand scanning: full 512-bit product, then 4 Montgomery reduction steps
+    // coarsely integrated operand scanning (CIOS), fully unrolled: row i of the product and its Montgomery step share one pass
+    // over a 5-word accumulator (a * b + t + carry never exceeds 128 bits)
     static inline F4 mul(const F4& a, const F4& b) {
-        u64 t[9] = {0};
+        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#pragma GCC unroll 4
         for (int i = 0; i < 4; i++) {
-            u128 c = 0;
-            for (int j = 0; j < 4; j++) { c += (u128)a.v[i] * b.v[j] + t[i + j]; t[i + j] = (u64)c; c >>= 64; }
-            t[i + 4] = (u64)c;
+            const u64 ai = a.v[i];
+            u128 c = (u128)ai * b.v[0] + t0; t0 = (u64)c; c >>= 64;
+            c += (u128)ai * b.v[1] + t1; t1 = (u64)c; c >>= 64;
+            c += (u128)ai * b.v[2] + t2; t2 = (u64)c; c >>= 64;
+            c += (u128)ai * b.v[3] + t3; t3 = (u64)c; c >>= 64;
+            c += t4; t4 = (u64)c;
+            const u64 t5 = (u64)(c >> 64);
+            const u64 m = t0 * P::NINV64;
+            c = (u128)m * P::P64[0] + t0; c >>= 64;
+            c += (u128)m * P::P64[1] + t1; t0 = (u64)c; c >>= 64;
+            c += (u128)m * P::P64[2] + t2; t1 = (u64)c; c >>= 64;
+            c += (u128)m * P::P64[3] + t3; t2 = (u64)c; c >>= 64;
+            c += t4; t3 = (u64)c; t4 = t5 + (u64)(c >> 64);
         }
-        u64 top = 0;
-        for (int i = 0; i < 4; i++) {
-            u64 m = t[i] * P::NINV64;
-            u128 c = 0;
-            for (int j = 0; j < 4; j++) { c += (u128)m * P::P64[j] + t[i + j]; t[i + j] = (u64)c; c >>= 64; }
-            for (int j = i + 4; j < 8 && c; j++) { c += t[j]; t[j] = (u64)c; c >>= 64; }
-            top += (u64)c;
-        }
-        F4 r = {{t[4], t[5], t[6], t[7]}};
-        if (top || geq_p(r.v)) sub_p(r.v);
+        F4 r = {{t0, t1, t2, t3}};
+        if (t4 || geq_p(r.v)) sub_p(r.v);
         return r;
     }
     static inline F4 sqr(const F4& a) { return mul(a, a); }

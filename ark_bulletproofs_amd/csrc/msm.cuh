@@ -628,6 +628,13 @@ template <class C> __device__ __forceinline__ Jac block_sum_jac(Jac acc, u32* __
     }
     return acc;
 }
+// a lane's point from `o` lanes further down its group of `width` lanes
+__device__ __forceinline__ Jac jac_shfl_down(const Jac& a, int o, int width = 64) {
+    Jac r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r.X.l[i] = __shfl_down(a.X.l[i], o, width); r.Y.l[i] = __shfl_down(a.Y.l[i], o, width); r.Z.l[i] = __shfl_down(a.Z.l[i], o, width); }
+    return r;
+}
 // 5b. special buckets: one workgroup sums ALL level-spl partials of its bucket into the bucket's single slot of the next level
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_reduce_special(const u32* __restrict__ in, const u32* __restrict__ off1, const u32* __restrict__ off2, u32* __restrict__ out, u32 b_gen, u32 B) {
@@ -743,6 +750,281 @@ k_msm_sum_partials(const u32* __restrict__ T_in, u32 count, u32* __restrict__ T_
         if (inf) { for (int i = 0; i < 8; i++) wd[i] = 0; } else fe_store_ark<F>(wd, acc.Z);
         store_words8(T_out + 16, wd);
     }
+}
+
+// ---- 7. The fixed-shape pipeline for mid-size MSMs (2^6 .. 2^18 terms, bit-marginal aggregation) ---------------------------------------
+// The general path above sizes its launches from the level totals, i.e. the host waits for the scans in the middle of every MSM, and
+// walks a tree of K launches whose depth is set by the fullest bucket.  For spread scalars (the Fiat-Shamir-derived vectors of the
+// IPA rounds, the usual case) the shape is known in advance:
+//   k_msm_bin_partition  as above
+//   k_msm_bin_sort_fs    the bin sort; it also emits each bucket's population, its chunk offset INSIDE the bin and the bin's chunk total
+//                        — no scan launches: a consumer scans the <= 1024 bin totals in LDS itself
+//   k_msm_accum_fs       one lane per 16-entry chunk; the grid is the upper bound n*W/16 + B, lanes past the device-side total leave
+//   k_msm_reduce_fs      one lane per bucket of the binned windows: <= 16 partials -> dense bucket sums
+//   k_msm_marginals_fs   bit marginals of the binned windows from the dense sums; the narrow top window (a few buckets holding n/2^bits
+//                        entries each) is summed straight from its level-1 partials, MSM_TOP_PARTS workgroups per bit, instead of
+//                        stretching a tree for its sake; copies and clears the overflow flag into the result block
+// One D2H copy, one wait, the host Horner tail.  A bucket above 256 entries or a full bin raises the flag: the MSM is then redone by
+// the general path (skew-tolerant).  Results are identical either way (a sum of the same group elements).
+static constexpr u32 MSM_FS_MAXBINS = 1024;
+static constexpr u32 MSM_TOP_PARTS = 4;
+struct FsPlan {
+    u32 nbins;      // wb * NBIN (+ 1 when the slot window exists: the last "bin" is that window)
+    u32 has_top;    // the slot window (w = wb) exists
+    u32 top_bits;   // bit length of its largest |digit|
+    u32 max_chunks; // grid bound of k_msm_accum_fs
+};
+// exclusive scan of src[0..n) (n <= MSM_FS_MAXBINS) into sh[0..n], sh[n] = total; 256 lanes; sh has MSM_FS_MAXBINS + 1 words, ws 4
+__device__ __forceinline__ void fs_block_scan(const u32* __restrict__ src, u32 n, u32* __restrict__ sh, u32* __restrict__ ws) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    u32 v[4], run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const u32 x = tid * 4 + q; v[q] = x < n ? src[x] : 0u; run += v[q]; }
+    u32 incl = run;
+    for (int o = 1; o < 64; o <<= 1) { const u32 t2 = __shfl_up(incl, o); if ((int)lane >= o) incl += t2; }
+    if (lane == 63) ws[wv] = incl;
+    __syncthreads();
+    u32 excl = incl - run;
+    for (u32 q = 0; q < wv; q++) excl += ws[q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const u32 x = tid * 4 + q; if (x < n) sh[x] = excl; excl += v[q]; }
+    if (tid == 255) sh[n] = excl;
+    __syncthreads();
+}
+// grid (NBIN, wb + has_top).  Row wb (bin 0 only) is the slot window: hist -> bcnt / loff / boff, hist restored to zero.
+__global__ void __launch_bounds__(256)
+k_msm_bin_sort_fs(u32* __restrict__ ent, u32* __restrict__ bin_cur, u32* __restrict__ hist, u32* __restrict__ boff, u32* __restrict__ bcnt,
+                  u32* __restrict__ loff, u32* __restrict__ bin_chunks, u32* __restrict__ overflow, MsmPlan pl, BinPlan bp, SlotPlan sp, int chl) {
+    extern __shared__ u32 lds[];
+    const u32 w = blockIdx.y, bin = blockIdx.x, tid = threadIdx.x;
+    const u32 lane = tid & 63u, wv = tid >> 6;
+    const u32 chm = (1u << chl) - 1u;
+    if (w >= bp.wb) {
+        if (bin) return;
+        u32* wsum = lds;   // 4 wave sums
+        const u32 wt = (u32)pl.W - 1u, nbt = bp.top_nb;
+        const u32 per = (nbt + 255u) / 256u;
+        u32 runc = 0;
+        const u32 capt = sp.cap[wt];   // (a bucket that outgrew its slots raised the overflow flag; only the stored entries may be read)
+        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) runc += (min(hist[wt * pl.NB + x], capt) + chm) >> chl;
+        u32 incl = runc;
+        for (int o = 1; o < 64; o <<= 1) { const u32 t2 = __shfl_up(incl, o); if ((int)lane >= o) incl += t2; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        u32 excl = incl - runc;
+        for (u32 q = 0; q < wv; q++) excl += wsum[q];
+        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) {
+            const u32 b = wt * pl.NB + x;
+            const u32 cn = min(hist[b], capt);
+            hist[b] = 0;
+            bcnt[b] = cn;
+            loff[b] = excl;
+            boff[b] = sp.base[wt] + x * sp.cap[wt];
+            excl += (cn + chm) >> chl;
+        }
+        if (tid == 255) bin_chunks[bp.wb * bp.NBIN] = excl;
+        return;
+    }
+    const u32 NF = 1u << bp.LB;
+    u32* cnt = lds;            // NF counters, then cursors
+    u32* wsum = lds + NF;      // 4 + 4 wave sums
+    u32* buf = lds + NF + 8;   // cap entries
+    const size_t region = ((size_t)w * bp.NBIN + bin) * bp.cap;
+    const u32 n = min(bin_cur[w * bp.NBIN + bin], bp.cap);
+    for (u32 x = tid; x < NF; x += 256) cnt[x] = 0;
+    __syncthreads();
+    if (tid == 0) bin_cur[w * bp.NBIN + bin] = 0;
+    const u32 fmask = NF - 1u;
+    for (u32 x = tid; x < n; x += 256) {
+        const u32 e = ent[region + x];
+        buf[x] = e;
+        atomicAdd(&cnt[(e >> 1) & fmask], 1u);
+    }
+    __syncthreads();
+    const u32 per = (NF + 255u) / 256u;
+    u32 run = 0, runc = 0, big = 0;
+    for (u32 x = tid * per; x < min((tid + 1) * per, NF); x++) { const u32 cn = cnt[x]; run += cn; runc += (cn + chm) >> chl; big = max(big, cn); }
+    u32 incl = run, inclc = runc;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t2 = __shfl_up(incl, o), t3 = __shfl_up(inclc, o);
+        if ((int)lane >= o) { incl += t2; inclc += t3; }
+    }
+    if (lane == 63) { wsum[wv] = incl; wsum[4 + wv] = inclc; }
+    __syncthreads();
+    u32 excl = incl - run, exclc = inclc - runc;
+    for (u32 q = 0; q < wv; q++) { excl += wsum[q]; exclc += wsum[4 + q]; }
+    const u32 b0 = w * pl.NB + (bin << bp.LB);
+    for (u32 x = tid * per; x < min((tid + 1) * per, NF); x++) {
+        const u32 cn = cnt[x];
+        bcnt[b0 + x] = cn;
+        boff[b0 + x] = (u32)region + excl;
+        loff[b0 + x] = exclc;
+        cnt[x] = excl;
+        excl += cn;
+        exclc += (cn + chm) >> chl;
+    }
+    if (tid == 255) bin_chunks[w * bp.NBIN + bin] = exclc;
+    if (big > (1u << (2 * chl))) *overflow = 1u;   // more partials than k_msm_reduce_fs takes in one step
+    __syncthreads();
+    for (u32 x = tid; x < n; x += 256) {
+        const u32 e = buf[x];
+        const u32 pos = atomicAdd(&cnt[(e >> 1) & fmask], 1u);
+        ent[region + pos] = ((e >> (bp.LB + 1)) << 1) | (e & 1u);
+    }
+}
+// buckets of bin x: first bucket index and count
+__device__ __forceinline__ void fs_bin_range(u32 x, const MsmPlan& pl, const BinPlan& bp, u32& b0, u32& nb) {
+    if (x < bp.wb * bp.NBIN) { const u32 w = x / bp.NBIN, bin = x - w * bp.NBIN; b0 = w * (u32)pl.NB + (bin << bp.LB); nb = 1u << bp.LB; }
+    else { b0 = ((u32)pl.W - 1u) * (u32)pl.NB; nb = bp.top_nb; }
+}
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __restrict__ bcnt, const u32* __restrict__ loff, const u32* __restrict__ boff,
+               const u32* __restrict__ bin_chunks, u32* __restrict__ out, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32* __restrict__ info) {
+    __shared__ u32 base[MSM_FS_MAXBINS + 1];
+    __shared__ u32 ws[4];
+    fs_block_scan(bin_chunks, fp.nbins, base, ws);
+    const u32 total = min(base[fp.nbins], fp.max_chunks);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { info[0] = base[fp.nbins]; info[1] = base[fp.nbins - 1]; }   // chunks; first chunk of the last bin
+    const u32 j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= total) return;
+    u32 lo = 0, hi = fp.nbins;   // base[lo] <= j < base[hi]
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (base[mid] <= j) lo = mid; else hi = mid; }
+    const u32 jj = j - base[lo];
+    u32 b0, nb;
+    fs_bin_range(lo, pl, bp, b0, nb);
+    u32 l2 = 0, h2 = nb;         // loff[b0 + l2] <= jj; (h2 == nb or loff[b0 + h2] > jj)
+    while (h2 - l2 > 1) { const u32 mid = (l2 + h2) >> 1; if (loff[b0 + mid] <= jj) l2 = mid; else h2 = mid; }
+    const u32 b = b0 + l2;
+    const u32 s0 = boff[b];
+    const u32 beg = s0 + ((jj - loff[b]) << chl);
+    const u32 end = min(beg + (1u << chl), s0 + bcnt[b]);
+    Jac acc = jac_inf<C>();
+    if (beg < end) {
+        u32 ent = entries[beg];
+        Aff p = load_aff_dev(seg_base_ptr(segs, ent >> 1));
+        for (u32 e = beg; e < end; e++) {
+            u32 ent_n = ent;
+            Aff p_n = p;
+            if (e + 1 < end) {
+                ent_n = entries[e + 1];
+                p_n = load_aff_dev(seg_base_ptr(segs, ent_n >> 1));
+            }
+            acc = jac_madd<C>(acc, aff_cneg_lazy<C>(p, ent & 1));
+            ent = ent_n;
+            p = p_n;
+        }
+    }
+    store_jac_ws<C>(out + (size_t)j * 24, acc);
+}
+// four lanes per bucket of the binned windows: lane q of the group sums partials q, q + 4, .. (<= 2^chl in all), two shuffle levels
+// join them -> sums[b] (the identity when the bucket is empty)
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_reduce_fs(const u32* __restrict__ part, const u32* __restrict__ bcnt, const u32* __restrict__ loff, const u32* __restrict__ bin_chunks,
+                u32* __restrict__ sums, MsmPlan pl, BinPlan bp, FsPlan fp, int chl) {
+    __shared__ u32 base[MSM_FS_MAXBINS + 1];
+    __shared__ u32 ws[4];
+    fs_block_scan(bin_chunks, fp.nbins, base, ws);
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    const u32 nbk = bp.wb * (u32)pl.NB;
+    const u32 b = min(g >> 2, nbk - 1u), q = g & 3u;   // (whole groups stay in the shuffles; the surplus groups of the last block store nothing)
+    const u32 w = b / (u32)pl.NB, v = b - w * (u32)pl.NB;
+    const u32 first = base[w * bp.NBIN + (v >> bp.LB)] + loff[b];
+    u32 nch = min((bcnt[b] + (1u << chl) - 1u) >> chl, 1u << chl);
+    if (first + nch > fp.max_chunks) nch = 0;
+    // ONE inlined addition serves the serial steps and the two shuffle levels: a Jacobian addition is ~50 KB of straight-line code
+    // and the instruction cache (64 KB per CU pair) is what a latency-bound tree kernel runs out of first
+    Jac acc = jac_inf<C>();
+    u32 e = q;
+    int o = 0;   // 0: serial steps; 2, 1: shuffle levels; -1: done
+#pragma unroll 1
+    while (o >= 0) {
+        Jac other;
+        bool doit;
+        if (o == 0) {
+            doit = e < nch;
+            if (!__any(doit)) { o = 2; continue; }
+            if (doit) other = load_jac_ws(part + (size_t)(first + e) * 24);
+            e += 4;
+        } else {
+            other = jac_shfl_down(acc, o, 4);
+            doit = (int)q < o && q + (u32)o < nch;
+            o = o == 2 ? 1 : -1;
+        }
+        if (doit) acc = jac_add<C>(acc, other);
+    }
+    if (q == 0 && (g >> 2) < nbk) store_jac_ws<C>(sums + (size_t)b * 24, acc);
+}
+template <class C> __device__ __forceinline__ void store_T_ark(u32* __restrict__ o, const Jac& acc) {
+    typedef typename C::Fq F;
+    u32 wd[8];
+    const bool inf = jac_is_inf(acc);
+    fe_store_ark<F>(wd, acc.X); store_words8(o, wd);
+    fe_store_ark<F>(wd, acc.Y); store_words8(o + 8, wd);
+    if (inf) { for (int i = 0; i < 8; i++) wd[i] = 0; } else fe_store_ark<F>(wd, acc.Z);
+    store_words8(o + 16, wd);
+}
+// blocks [0, wb * c): (w, k) of the binned windows over the dense sums; then top_bits * MSM_TOP_PARTS blocks for the slot window, summing
+// the level-1 partials of the buckets whose value has bit k.  T_out[wb * c + k * MSM_TOP_PARTS + part]; info[2] = overflow flag (then cleared).
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, const u32* __restrict__ bcnt, const u32* __restrict__ loff,
+                   u32* __restrict__ T_out, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32* __restrict__ info, u32* __restrict__ overflow) {
+    __shared__ u32 pre[2052];      // slot window: prefix counts of the partials of the buckets with bit k (top_nb <= 2048)
+    __shared__ u32 wsum[4];
+    __shared__ u32 tree[256 * 27];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    constexpr u32 NT = 256;
+    const u32 ngen = bp.wb * (u32)pl.c;
+    if (blockIdx.x == 0 && tid == 0) { info[2] = *overflow; *overflow = 0; }
+    const bool generic = blockIdx.x < ngen;
+    u32 w = 0, k = 0, it, it_end, it_step;
+    const u32 b0t = ((u32)pl.W - 1u) * (u32)pl.NB, nbt = bp.top_nb;
+    u32 top_first = 0;
+    if (generic) {
+        w = blockIdx.x / (u32)pl.c; k = blockIdx.x - w * (u32)pl.c;
+        it = tid; it_end = (u32)pl.NB; it_step = NT;
+    } else {
+        // slot window: a flat list of the partials of the buckets with bit k, dealt to MSM_TOP_PARTS * 256 lanes
+        const u32 t = blockIdx.x - ngen;
+        k = t / MSM_TOP_PARTS;
+        const u32 prt = t - k * MSM_TOP_PARTS;
+        const u32 per = (nbt + NT - 1u) / NT;
+        const u32 chm = (1u << chl) - 1u;
+        u32 run = 0;
+        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) run += (((x + 1) >> k) & 1u) ? (bcnt[b0t + x] + chm) >> chl : 0u;
+        u32 incl = run;
+        for (int o = 1; o < 64; o <<= 1) { const u32 t2 = __shfl_up(incl, o); if ((int)lane >= o) incl += t2; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        u32 excl = incl - run;
+        for (u32 q = 0; q < wv; q++) excl += wsum[q];
+        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) { pre[x] = excl; excl += (((x + 1) >> k) & 1u) ? (bcnt[b0t + x] + chm) >> chl : 0u; }
+        if (tid == NT - 1u) pre[nbt] = excl;
+        __syncthreads();
+        it = prt * NT + tid; it_end = pre[nbt]; it_step = MSM_TOP_PARTS * NT;
+        top_first = info[1];   // (written by k_msm_accum_fs, an earlier launch on this stream)
+    }
+    // serial steps (one addition site for both kinds of block), then the LDS tree over the 256 lanes
+    Jac acc = jac_inf<C>();
+#pragma unroll 1
+    while (true) {
+        const u32* src = nullptr;
+        if (generic) {
+            while (it < it_end && !src) {
+                if (((it + 1) >> k) & 1u) { const u32 b = w * (u32)pl.NB + it; if (bcnt[b]) src = sums + (size_t)b * 24; }
+                it += it_step;
+            }
+        } else if (it < it_end) {
+            u32 lo = 0, hi = nbt;   // pre[lo] <= it < pre[hi]
+            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (pre[mid] <= it) lo = mid; else hi = mid; }
+            const u32 idx = top_first + loff[b0t + lo] + (it - pre[lo]);
+            if (idx < fp.max_chunks) src = part + (size_t)idx * 24;
+            it += it_step;
+        }
+        if (!__any(src != nullptr)) break;
+        if (src) acc = jac_add<C>(acc, load_jac_ws(src));
+    }
+    acc = block_sum_jac<C>(acc, tree);
+    if (tid == 0) store_T_ark<C>(T_out + (size_t)blockIdx.x * 24, acc);
 }
 
 // ---- wire codec: ark-serialize compressed SW points (x as 8 Montgomery words + flag byte) -> affine, ark layout ----------

@@ -193,7 +193,10 @@ def run_msm(args, rank, world, local):
                                  rank, world, device=COLL_DEVICE if world > 1 else None)
         else:
             # term-sharded MSM: local partial, all-gather of one 64-byte point per rank over RCCL, host point-reduce
-            P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device=COLL_DEVICE if world > 1 else None)
+            if world == 1:
+                eng.msm_dev(db, ds, n)   # (one rank: the local MSM is the result)
+            else:
+                P.sharded_msm(args.curve, lambda: eng.msm_dev(db, ds, n), E.host_points_sum, device=COLL_DEVICE)
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     acc_ms, acc_n = eng.kernel_time(0)
