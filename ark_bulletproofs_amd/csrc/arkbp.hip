@@ -325,7 +325,6 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         return nslots;
     };
     SlotPlan sp;
-    ScopedK total(ctx, BP_K_MSM_TOTAL);
     u32* lvl = ctx->lvl_off.as<u32>();
     u32* d_tot = ctx->totals.as<u32>();
     u32* d_tiles = d_tot + (NL + 2);
@@ -381,10 +380,12 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         fp.nbins = bp.wb * bp.NBIN + fp.has_top;
         if (fp.has_top) { u32 t = bp.top_nb; while (t) { fp.top_bits++; t >>= 1; } }
         const size_t nwin = (size_t)(pl.w_hi - pl.w_lo);
+        const u32 red_g = (size_t)bp.wb * pl.NB > 49152 ? 1u : 4u;   // lanes per bucket of k_msm_reduce_fs: groups while the lanes fit the chip at once, one lane per bucket beyond
         const size_t maxch = ((n * nwin) >> chl_fs) + std::min<size_t>(n * nwin, nwin * (size_t)pl.NB) + 64;
         fp.max_chunks = (u32)maxch;
         const size_t nslots = make_slots(sp, (int)bp.wb, (size_t)bp.wb * bp.NBIN * bp.cap);
-        const size_t tc = (size_t)bp.wb * pl.c + (size_t)fp.top_bits * MSM_TOP_PARTS;
+        fp.top_parts = (u32)std::min<size_t>(MSM_TOP_PARTS_MAX, std::max<size_t>(4, n >> 15));
+        const size_t tc = (size_t)bp.wb * pl.c + (size_t)fp.top_bits * fp.top_parts;
         const size_t tb = tc * 96 + 64;
         if (nslots < ((size_t)1 << 32) && maxch < ((size_t)1 << 31)) {
             BPCHK(ctx->slots.ensure(nslots * 4));
@@ -419,10 +420,10 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
                 hipLaunchKernelGGL(k_msm_accum_fs<C>, dim3((u32)((maxch + 255) / 256)), dim3(256), 0, st, segs, ctx->slots.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                                    ctx->boff.as<u32>(), ctx->fs_binch.as<u32>(), ctx->lvA.as<u32>(), pl, bp, fp, chl_fs, d_info);
             }
-            hipLaunchKernelGGL(k_msm_reduce_fs<C>, dim3((u32)(((size_t)bp.wb * pl.NB * 4 + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
-                               ctx->fs_binch.as<u32>(), ctx->fs_sums.as<u32>(), pl, bp, fp, chl_fs);
-            hipLaunchKernelGGL(k_msm_marginals_fs<C>, dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
-                               ctx->Tbuf.as<u32>(), pl, bp, fp, chl_fs, d_info, d_over);
+            hipLaunchKernelGGL(k_msm_reduce_fs<C>, dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+                               ctx->fs_binch.as<u32>(), ctx->fs_sums.as<u32>(), pl, bp, fp, chl_fs, red_g);
+            hipLaunchKernelGGL((k_msm_marginals_fs<C, 256>), dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+                           ctx->Tbuf.as<u32>(), pl, bp, fp, chl_fs, d_info, d_over);
             HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tb, hipMemcpyDeviceToHost, st));
             total.stop();
             const double t_f1 = mtrace ? tfs() : 0;
@@ -441,7 +442,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
                 const int ngen = (int)bp.wb * pl.c;
                 for (int j = ngen + (int)fp.top_bits - 1; j >= 0; j--) {
                     acc = G::dbl(acc);
-                    if (j >= ngen) { for (u32 q = 0; q < MSM_TOP_PARTS; q++) add_T((size_t)ngen + (size_t)(j - ngen) * MSM_TOP_PARTS + q); }
+                    if (j >= ngen) { for (u32 q = 0; q < fp.top_parts; q++) add_T((size_t)ngen + (size_t)(j - ngen) * fp.top_parts + q); }
                     else add_T((size_t)j);
                 }
                 result = acc;
@@ -452,6 +453,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
             if (mtrace) fprintf(stderr, "[msm-fs] n=%zu: overflow, the general path takes over\n", n);
         }
     }
+    ScopedK total(ctx, BP_K_MSM_TOTAL);
     const auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_m0 = mtrace ? tnow() : 0;
     BPCHK(front_end(binned));

@@ -610,18 +610,18 @@ k_msm_reduce(const u32* __restrict__ in, const u32* __restrict__ off_prev, const
 }
 
 // sum of the 256 lanes' points, valid in lane 0.  LDS tree: limbs stored limb-major (27 rows of 256 words) so lanes hit distinct banks
-template <class C> __device__ __forceinline__ Jac block_sum_jac(Jac acc, u32* __restrict__ sh /* 256 * 27 words */) {
+template <class C, u32 NT = 256> __device__ __forceinline__ Jac block_sum_jac(Jac acc, u32* __restrict__ sh /* NT * 27 words */) {
     const u32 tid = threadIdx.x;
-    for (u32 stride = 128; stride >= 1; stride >>= 1) {
+    for (u32 stride = NT / 2; stride >= 1; stride >>= 1) {
         if (tid >= stride && tid < 2 * stride) {
 #pragma unroll
-            for (int i = 0; i < 9; i++) { sh[i * 256 + tid] = acc.X.l[i]; sh[(9 + i) * 256 + tid] = acc.Y.l[i]; sh[(18 + i) * 256 + tid] = acc.Z.l[i]; }
+            for (int i = 0; i < 9; i++) { sh[i * NT + tid] = acc.X.l[i]; sh[(9 + i) * NT + tid] = acc.Y.l[i]; sh[(18 + i) * NT + tid] = acc.Z.l[i]; }
         }
         __syncthreads();
         if (tid < stride) {
             Jac o;
 #pragma unroll
-            for (int i = 0; i < 9; i++) { o.X.l[i] = sh[i * 256 + tid + stride]; o.Y.l[i] = sh[(9 + i) * 256 + tid + stride]; o.Z.l[i] = sh[(18 + i) * 256 + tid + stride]; }
+            for (int i = 0; i < 9; i++) { o.X.l[i] = sh[i * NT + tid + stride]; o.Y.l[i] = sh[(9 + i) * NT + tid + stride]; o.Z.l[i] = sh[(18 + i) * NT + tid + stride]; }
             acc = jac_add<C>(acc, o);
         }
         __syncthreads();
@@ -758,37 +758,38 @@ k_msm_sum_partials(const u32* __restrict__ T_in, u32 count, u32* __restrict__ T_
 // IPA rounds, the usual case) the shape is known in advance:
 //   k_msm_bin_partition  as above
 //   k_msm_bin_sort_fs    the bin sort; it also emits each bucket's population, its chunk offset INSIDE the bin and the bin's chunk total
-//                        — no scan launches: a consumer scans the <= 1024 bin totals in LDS itself
+//                        — no scan launches: a consumer scans the <= 4096 bin totals in LDS itself
 //   k_msm_accum_fs       one lane per 16-entry chunk; the grid is the upper bound n*W/16 + B, lanes past the device-side total leave
 //   k_msm_reduce_fs      one lane per bucket of the binned windows: <= 16 partials -> dense bucket sums
 //   k_msm_marginals_fs   bit marginals of the binned windows from the dense sums; the narrow top window (a few buckets holding n/2^bits
-//                        entries each) is summed straight from its level-1 partials, MSM_TOP_PARTS workgroups per bit, instead of
+//                        entries each) is summed straight from its level-1 partials, 4 .. 32 workgroups per bit, instead of
 //                        stretching a tree for its sake; copies and clears the overflow flag into the result block
 // One D2H copy, one wait, the host Horner tail.  A bucket above 256 entries or a full bin raises the flag: the MSM is then redone by
 // the general path (skew-tolerant).  Results are identical either way (a sum of the same group elements).
-static constexpr u32 MSM_FS_MAXBINS = 1024;
-static constexpr u32 MSM_TOP_PARTS = 4;
+static constexpr u32 MSM_FS_MAXBINS = 4096;
+static constexpr u32 MSM_TOP_PARTS_MAX = 32;   // (a bit of the slot window collects ~n/32 partials: 4 .. 32 workgroups share them)
 struct FsPlan {
     u32 nbins;      // wb * NBIN (+ 1 when the slot window exists: the last "bin" is that window)
     u32 has_top;    // the slot window (w = wb) exists
     u32 top_bits;   // bit length of its largest |digit|
     u32 max_chunks; // grid bound of k_msm_accum_fs
+    u32 top_parts;  // workgroups per bit of the slot window in k_msm_marginals_fs
 };
 // exclusive scan of src[0..n) (n <= MSM_FS_MAXBINS) into sh[0..n], sh[n] = total; 256 lanes; sh has MSM_FS_MAXBINS + 1 words, ws 4
 __device__ __forceinline__ void fs_block_scan(const u32* __restrict__ src, u32 n, u32* __restrict__ sh, u32* __restrict__ ws) {
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    u32 v[4], run = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) { const u32 x = tid * 4 + q; v[q] = x < n ? src[x] : 0u; run += v[q]; }
+    const u32 per = (n + 255u) >> 8;
+    const u32 x0 = tid * per, x1 = min(x0 + per, n);
+    u32 run = 0;
+    for (u32 x = x0; x < x1; x++) run += src[x];
     u32 incl = run;
     for (int o = 1; o < 64; o <<= 1) { const u32 t2 = __shfl_up(incl, o); if ((int)lane >= o) incl += t2; }
     if (lane == 63) ws[wv] = incl;
     __syncthreads();
     u32 excl = incl - run;
     for (u32 q = 0; q < wv; q++) excl += ws[q];
-#pragma unroll
-    for (int q = 0; q < 4; q++) { const u32 x = tid * 4 + q; if (x < n) sh[x] = excl; excl += v[q]; }
-    if (tid == 255) sh[n] = excl;
+    for (u32 x = x0; x < x1; x++) { sh[x] = excl; excl += src[x]; }
+    if (tid == 255) sh[n] = excl;   // (the last lane's range ends at n, or is empty and then excl is the grand total)
     __syncthreads();
 }
 // grid (NBIN, wb + has_top).  Row wb (bin 0 only) is the slot window: hist -> bcnt / loff / boff, hist restored to zero.
@@ -916,23 +917,23 @@ k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __rest
     }
     store_jac_ws<C>(out + (size_t)j * 24, acc);
 }
-// four lanes per bucket of the binned windows: lane q of the group sums partials q, q + 4, .. (<= 2^chl in all), two shuffle levels
-// join them -> sums[b] (the identity when the bucket is empty)
+// G lanes per bucket of the binned windows (G = 4, or 1 when the buckets alone fill the chip): lane q of the group sums partials
+// q, q + G, .. (<= 2^chl in all), lg G shuffle levels join them -> sums[b] (the identity when the bucket is empty)
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_reduce_fs(const u32* __restrict__ part, const u32* __restrict__ bcnt, const u32* __restrict__ loff, const u32* __restrict__ bin_chunks,
-                u32* __restrict__ sums, MsmPlan pl, BinPlan bp, FsPlan fp, int chl) {
+                u32* __restrict__ sums, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32 G) {
     __shared__ u32 base[MSM_FS_MAXBINS + 1];
     __shared__ u32 ws[4];
     fs_block_scan(bin_chunks, fp.nbins, base, ws);
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     const u32 nbk = bp.wb * (u32)pl.NB;
-    const u32 b = min(g >> 2, nbk - 1u), q = g & 3u;   // (whole groups stay in the shuffles; the surplus groups of the last block store nothing)
+    const u32 gb = G == 4 ? g >> 2 : g;
+    const u32 b = min(gb, nbk - 1u), q = G == 4 ? g & 3u : 0u;   // (whole groups stay in the shuffles; the surplus groups of the last block store nothing)
     const u32 w = b / (u32)pl.NB, v = b - w * (u32)pl.NB;
     const u32 first = base[w * bp.NBIN + (v >> bp.LB)] + loff[b];
     u32 nch = min((bcnt[b] + (1u << chl) - 1u) >> chl, 1u << chl);
     if (first + nch > fp.max_chunks) nch = 0;
-    // ONE inlined addition serves the serial steps and the two shuffle levels: a Jacobian addition is ~50 KB of straight-line code
-    // and the instruction cache (64 KB per CU pair) is what a latency-bound tree kernel runs out of first
+    // ONE inlined addition serves the serial steps and the shuffle levels: a Jacobian addition is ~50 KB of straight-line code
     Jac acc = jac_inf<C>();
     u32 e = q;
     int o = 0;   // 0: serial steps; 2, 1: shuffle levels; -1: done
@@ -942,9 +943,9 @@ k_msm_reduce_fs(const u32* __restrict__ part, const u32* __restrict__ bcnt, cons
         bool doit;
         if (o == 0) {
             doit = e < nch;
-            if (!__any(doit)) { o = 2; continue; }
+            if (!__any(doit)) { o = G == 4 ? 2 : -1; continue; }
             if (doit) other = load_jac_ws(part + (size_t)(first + e) * 24);
-            e += 4;
+            e += G;
         } else {
             other = jac_shfl_down(acc, o, 4);
             doit = (int)q < o && q + (u32)o < nch;
@@ -952,7 +953,7 @@ k_msm_reduce_fs(const u32* __restrict__ part, const u32* __restrict__ bcnt, cons
         }
         if (doit) acc = jac_add<C>(acc, other);
     }
-    if (q == 0 && (g >> 2) < nbk) store_jac_ws<C>(sums + (size_t)b * 24, acc);
+    if (q == 0 && gb < nbk) store_jac_ws<C>(sums + (size_t)b * 24, acc);
 }
 template <class C> __device__ __forceinline__ void store_T_ark(u32* __restrict__ o, const Jac& acc) {
     typedef typename C::Fq F;
@@ -963,16 +964,15 @@ template <class C> __device__ __forceinline__ void store_T_ark(u32* __restrict__
     if (inf) { for (int i = 0; i < 8; i++) wd[i] = 0; } else fe_store_ark<F>(wd, acc.Z);
     store_words8(o + 16, wd);
 }
-// blocks [0, wb * c): (w, k) of the binned windows over the dense sums; then top_bits * MSM_TOP_PARTS blocks for the slot window, summing
-// the level-1 partials of the buckets whose value has bit k.  T_out[wb * c + k * MSM_TOP_PARTS + part]; info[2] = overflow flag (then cleared).
-template <class C> __global__ void __launch_bounds__(256)
+// blocks [0, wb * c): (w, k) of the binned windows over the dense sums; then top_bits * top_parts blocks for the slot window, summing
+// the level-1 partials of the buckets whose value has bit k.  T_out[wb * c + k * top_parts + part]; info[2] = overflow flag (then cleared).
+template <class C, u32 NT> __global__ void __launch_bounds__(NT)
 k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, const u32* __restrict__ bcnt, const u32* __restrict__ loff,
                    u32* __restrict__ T_out, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32* __restrict__ info, u32* __restrict__ overflow) {
     __shared__ u32 pre[2052];      // slot window: prefix counts of the partials of the buckets with bit k (top_nb <= 2048)
-    __shared__ u32 wsum[4];
-    __shared__ u32 tree[256 * 27];
+    __shared__ u32 wsum[NT / 64];
+    __shared__ u32 tree[NT * 27];
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    constexpr u32 NT = 256;
     const u32 ngen = bp.wb * (u32)pl.c;
     if (blockIdx.x == 0 && tid == 0) { info[2] = *overflow; *overflow = 0; }
     const bool generic = blockIdx.x < ngen;
@@ -983,10 +983,10 @@ k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, c
         w = blockIdx.x / (u32)pl.c; k = blockIdx.x - w * (u32)pl.c;
         it = tid; it_end = (u32)pl.NB; it_step = NT;
     } else {
-        // slot window: a flat list of the partials of the buckets with bit k, dealt to MSM_TOP_PARTS * 256 lanes
+        // slot window: a flat list of the partials of the buckets with bit k, dealt to fp.top_parts * 256 lanes
         const u32 t = blockIdx.x - ngen;
-        k = t / MSM_TOP_PARTS;
-        const u32 prt = t - k * MSM_TOP_PARTS;
+        k = t / fp.top_parts;
+        const u32 prt = t - k * fp.top_parts;
         const u32 per = (nbt + NT - 1u) / NT;
         const u32 chm = (1u << chl) - 1u;
         u32 run = 0;
@@ -1000,7 +1000,7 @@ k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, c
         for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) { pre[x] = excl; excl += (((x + 1) >> k) & 1u) ? (bcnt[b0t + x] + chm) >> chl : 0u; }
         if (tid == NT - 1u) pre[nbt] = excl;
         __syncthreads();
-        it = prt * NT + tid; it_end = pre[nbt]; it_step = MSM_TOP_PARTS * NT;
+        it = prt * NT + tid; it_end = pre[nbt]; it_step = fp.top_parts * NT;
         top_first = info[1];   // (written by k_msm_accum_fs, an earlier launch on this stream)
     }
     // serial steps (one addition site for both kinds of block), then the LDS tree over the 256 lanes
@@ -1023,7 +1023,7 @@ k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, c
         if (!__any(src != nullptr)) break;
         if (src) acc = jac_add<C>(acc, load_jac_ws(src));
     }
-    acc = block_sum_jac<C>(acc, tree);
+    acc = block_sum_jac<C, NT>(acc, tree);
     if (tid == 0) store_T_ark<C>(T_out + (size_t)blockIdx.x * 24, acc);
 }
 
