@@ -80,6 +80,25 @@ def test_msm_small(eng, oracle, n):
     assert (eng.msm(bases, sc) == O.msm(cv, bases, sc)).all()
 
 
+def test_msm_skew_falls_back_from_fixed_shape_pipeline(eng, oracle):
+    """The fixed-shape MSM pipeline (msm.cuh 7) serves spread scalars; a bucket above 256 entries or a full bin region raises its
+    overflow flag and the general path redoes the MSM.  Both kinds of skew, and the spread case at the same size, against the oracle."""
+    O, cv = oracle, eng.curve
+    FR = O.fid(cv, True)
+    n = 5000
+    G, H = O.bp_gens(cv, n // 2)
+    bases = np.concatenate([G, H])
+    rnd = _rand_scalars(O, cv, n, 7)
+    assert (eng.msm(bases, rnd) == O.msm(cv, bases, rnd)).all()
+    # 0/1/2 witness-like scalars: whole windows in one or two buckets
+    small = np.array([O.fe_from_int(FR, (i * 7 + 3) % 3) for i in range(n)])
+    assert (eng.msm(bases, small) == O.msm(cv, bases, small)).all()
+    # half spread, half one repeated full-size scalar: the bins hold, single buckets outgrow the reduce step
+    mixed = rnd.copy()
+    mixed[n // 2:] = rnd[11]
+    assert (eng.msm(bases, mixed) == O.msm(cv, bases, mixed)).all()
+
+
 def test_msm_edge_cases(eng, oracle):
     O, cv = oracle, eng.curve
     FR = O.fid(cv, True)
