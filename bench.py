@@ -524,6 +524,7 @@ def run_verify(args, rank, world, local):
     t0 = time.perf_counter()
     tms = np.zeros(5)
     ok = True
+    steps_profiled = [args.steps if nfl == 1 else 0]
     if nfl == 1:
         for _ in range(args.steps):
             rc, tm, pt = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
@@ -543,6 +544,8 @@ def run_verify(args, rank, world, local):
                 rc, tm, pt = e.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
                 oks.append(rc == 0 and not pt.any())
                 tml.append(tm)
+                if e is eng:
+                    steps_profiled[0] += 1   # (only the first ctx records kernel events)
 
         run_threads([(worker, (e,)) for e in engs])
         ok = all(oks) and len(oks) == args.steps
@@ -575,7 +578,7 @@ def run_verify(args, rank, world, local):
         # k_vfy_batch (one launch per block of proofs): per proof it stands for the reference's scalar generation (64*N B written, 96*N B of
         # wL/wR/wO read) — 160*N algorithmic bytes per proof; the fused kernel itself reads only the 3.3 KB parameter
         # block per proof and the shared CSC, and writes chunk partials
-        nproofs_per_launch = inst.n * args.steps / max(vs_n, 1)  # the batch goes through in blocks of 512 proofs, one k_vfy_batch launch each
+        nproofs_per_launch = inst.n * steps_profiled[0] / max(vs_n, 1)  # the batch goes through in blocks of 512 proofs, one k_vfy_batch launch each
         res["roofline"] = {"bound": "hbm", "kernel": "k_vfy_batch (one launch per block of 512 proofs)", "achieved": 160.0 * N * nproofs_per_launch / avg_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * N * nproofs_per_launch / avg_s / 1e9 / HBM_PEAK_GBS,
                            "traffic": pmc_traffic("verify4096/k_vfy_batch<Secq>", args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512 and not shuffle_k, "r02_pmc_verify4096_summary.json"),
@@ -634,7 +637,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
-    ap.add_argument("--verify-inflight", type=int, default=2, help="verify workload: batch_verify calls in flight per GPU (own ctx each)")
+    ap.add_argument("--verify-inflight", type=int, default=1, help="verify workload: batch_verify calls in flight per GPU (own ctx each); measured: 2 in flight are not faster than 1")
     ap.add_argument("--shuffle-k", type=int, default=0, help="verify workload: batches of k-shuffle proofs (the reference's two-phase benchmark circuit) instead of cfg4's range proofs")
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
