@@ -211,8 +211,8 @@ def run_msm(args, rank, world, local):
     }
     if acc_n:
         avg_s = acc_ms / acc_n * 1e-3
-        res["roofline"] = {"bound": "hbm", "kernel": "k_msm_accum", "achieved": n * 96 / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": n * 96 / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("msm/k_msm_accum<Secq>", n == 1 << 16 and args.curve == 0, "r02_pmc_msm_summary.json"),
+        res["roofline"] = {"bound": "hbm", "kernel": "k_msm_accum_fs (k_msm_accum above 2^18 buckets)", "achieved": n * 96 / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": n * 96 / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("msm/k_msm_accum_fs<Secq>", n == 1 << 16 and args.curve == 0, "r02_pmc_msm_summary.json"),
                            "avg_kernel_ms": acc_ms / acc_n,
                            "msm_all_kernels_ms": tot_ms / max(tot_n, 1)}
         W, c = E.msm_window_count(args.curve, n)
