@@ -154,6 +154,7 @@ struct bp_ctx {
     void* gather_user = nullptr;
     size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
     size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
+    size_t tune_host_threads = 0;                  // BP_TUNE_HOST_THREADS: size of this ctx's host pool (0 = host_pool_threads())
     DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
     // fixed-base MSM rows of the generators (bp_gens_msm_tables): row r of a table = 2^(4r) * base, r < FB_ROWS, layout [r][i]
     DevBuf fb_G, fb_H, fb_pc;
@@ -1829,6 +1830,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
     switch (knob) {
         case BP_TUNE_CYCLIC_MIN: c->tune_cyclic_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_FIXED_MIN: c->tune_msm_fixed_min = (size_t)value; return BP_OK;
+        case BP_TUNE_HOST_THREADS: if (value > 256) return BP_E_ARG; c->tune_host_threads = (size_t)value; c->pool.reset(); return BP_OK;
         case BP_TUNE_FOLD_BATCH_MIN: c->tune_fold_batch_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_BIN_MIN: c->tune_msm_bin_min = (size_t)value; return BP_OK;
         case BP_TUNE_IPA_FREEZE_LEN: c->tune_ipa_freeze_len = (size_t)value; return BP_OK;

@@ -140,7 +140,7 @@ class Engine:
         check(lib().bp_ctx_set_shard_allgather(self.ctx, self._gather_cb, None), "bp_ctx_set_shard_allgather")
 
     def set_tuning(self, knob, value):
-        """knob: 0 fold-batch minimum lanes, 1 MSM two-level-sort minimum terms (include/arkbp.h BP_TUNE_*)"""
+        """knob: 0 fold-batch minimum lanes, 1 MSM two-level-sort minimum terms, .. 6 host threads of the ctx's pool (include/arkbp.h BP_TUNE_*)"""
         check(lib().bp_ctx_set_tuning(self.ctx, int(knob), C.c_uint64(int(value))), "bp_ctx_set_tuning")
 
     # ---- profiling ------------------------------------------------------------------------------

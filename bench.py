@@ -154,6 +154,21 @@ def synth_msm_inputs(eng, n, rank):
     return bases, sc
 
 
+def cpu_quota():
+    """CPUs this process may use: the cgroup's cpu.max quota when there is one (the GPU boxes allow 16 of their 256 hardware
+    threads per GPU), else the affinity mask"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def pmc_traffic(keys, applicable, fname, field="largest"):
     """HBM bytes from the committed rocprofv3 PMC passes (profiles/<fname>, made by tools/pmc_summary.py from FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same workload).  FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950
@@ -515,16 +530,19 @@ def run_verify(args, rank, world, local):
         e2 = A.Engine(curve=args.curve, device=local)
         e2.share_gens_from(eng)
         engs.append(e2)
+    if nfl > 1 and not os.environ.get("ARKBP_HOST_THREADS"):
+        # several pools share the cores this process may use (measured on a 16-CPU cgroup: 2 x 12 threads 177 K proofs/s, 2 x 24 168 K,
+        # 2 x 8 151 K, 1 x 32 162 K)
+        per_pool = max(4, int(round(cpu_quota() * 1.5 / nfl)))
+        for e in engs:
+            e.set_tuning(6, per_pool)   # BP_TUNE_HOST_THREADS
     for _ in range(args.warmup):
         for e in engs:
             e.batch_verify(inst, seed, alpha_skip=lo)
-    eng.set_profiling(True)
-    eng.reset_profiling()
     barrier(world)
     t0 = time.perf_counter()
     tms = np.zeros(5)
     ok = True
-    steps_profiled = [args.steps if nfl == 1 else 0]
     if nfl == 1:
         for _ in range(args.steps):
             rc, tm, pt = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
@@ -544,8 +562,6 @@ def run_verify(args, rank, world, local):
                 rc, tm, pt = e.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
                 oks.append(rc == 0 and not pt.any())
                 tml.append(tm)
-                if e is eng:
-                    steps_profiled[0] += 1   # (only the first ctx records kernel events)
 
         run_threads([(worker, (e,)) for e in engs])
         ok = all(oks) and len(oks) == args.steps
@@ -555,6 +571,13 @@ def run_verify(args, rank, world, local):
     assert ok, "batch verification of valid proofs failed"
     for e in engs[1:]:
         e.close()
+    # kernel times for the roofline: ONE batch run alone after the timed region (HIP events on the ctx's stream; with batches in
+    # flight a launch's duration would include its neighbour's share of the GPU)
+    eng.set_profiling(True)
+    eng.reset_profiling()
+    rc, _, _ = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
+    assert rc == 0
+    steps_profiled = [1]
     k = int(np.log2(N))
     m_commit = 2 * shuffle_k if shuffle_k else nval
     per_proof_bytes = 352 * N + 96 * (13 + m_commit + 2 * k)
@@ -637,7 +660,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
-    ap.add_argument("--verify-inflight", type=int, default=1, help="verify workload: batch_verify calls in flight per GPU (own ctx each); measured: 2 in flight are not faster than 1")
+    ap.add_argument("--verify-inflight", type=int, default=2, help="verify workload: batch_verify calls in flight per GPU (own ctx and host pool each; the pools divide the process's CPU quota)")
     ap.add_argument("--shuffle-k", type=int, default=0, help="verify workload: batches of k-shuffle proofs (the reference's two-phase benchmark circuit) instead of cfg4's range proofs")
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")

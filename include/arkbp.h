@@ -363,6 +363,9 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
 #define BP_TUNE_MSM_WSUM_MIN 3
 #define BP_TUNE_CYCLIC_MIN 4   /* padded size from which a sharded prover partitions the IPA index-cyclically (default 2^14) */
 #define BP_TUNE_MSM_FIXED_MIN 5   /* terms from which an MSM over the generator tables uses the fixed-base rows (default 2^20; >= 4096) */
+#define BP_TUNE_HOST_THREADS 6    /* host threads of this ctx's pool for the per-instance transcript replays of batch verification (0 = default:
+                                     the machine's hardware threads, at most 32, or ARKBP_HOST_THREADS); callers that keep several batches in
+                                     flight on several ctxs divide the cores among them */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 
 /* The O(N) part of `Verifier::verification_scalars` (src/r1cs/verifier.rs:465-514, s from inner_product_proof.rs:279-311) for a
