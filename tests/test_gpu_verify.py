@@ -222,6 +222,55 @@ def test_batch_pipeline_many_blocks(eng, oracle):
         assert rc == E_VERIFICATION
 
 
+def test_two_batches_in_flight_on_two_ctxs_with_divided_host_pools(eng, oracle):
+    """bench.py keeps two batch_verify calls in flight, each on its own ctx (shared generator tables) with a host pool of its
+    own size (BP_TUNE_HOST_THREADS): the same check points and decisions as one call at a time with the default pool."""
+    import threading
+
+    import ark_bulletproofs_amd as A
+
+    cv = eng.curve
+    kinds = [(3, [20, 0]), (1, [8, 200]), (0, [5])]
+    distinct = []
+    for i, (sc, prm) in enumerate(kinds):
+        pr = eng.prove_scenario(sc, prm, bytes([90 + i]) * 32, m_cap=32)
+        distinct.append((sc, prm, pr.proof, pr.commitments, pr.publics))
+    good = [distinct[(i * 5 + i // 64) % len(distinct)] for i in range(700)]
+    sc, prm, proof, cm, pb = good[650]
+    tampered = bytearray(proof)
+    tampered[11 * 33 + 40] ^= 4
+    bad = list(good)
+    bad[650] = (sc, prm, bytes(tampered), cm, pb)
+    seed = bytes([4]) * 32
+    rc0, _, p_good = eng.batch_verify(good, seed, want_point=True)
+    rc1, _, p_bad = eng.batch_verify(bad, seed, want_point=True)
+    assert rc0 == OK and rc1 == E_VERIFICATION and not p_good.any() and p_bad.any()
+    with pytest.raises(Exception):
+        eng.set_tuning(6, 100000)   # out of range
+    e2 = A.Engine(curve=cv)
+    e2.share_gens_from(eng)
+    try:
+        eng.set_tuning(6, 3)
+        e2.set_tuning(6, 2)
+        out = {}
+
+        def run(tag, e, inst):
+            out[tag] = [e.batch_verify(inst, seed, want_point=True) for _ in range(3)]
+
+        th = [threading.Thread(target=run, args=("a", eng, good)), threading.Thread(target=run, args=("b", e2, bad))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for rc, _, pt in out["a"]:
+            assert rc == OK and not pt.any()
+        for rc, _, pt in out["b"]:
+            assert rc == E_VERIFICATION and (pt == p_bad).all()
+    finally:
+        eng.set_tuning(6, 0)
+        e2.close()
+
+
 def test_verification_gh_scalars_match_reference_formulas(eng, oracle):
     """bp_r1cs_verification_gh against an independent big-integer evaluation of verifier.rs:465-514 / inner_product_proof.rs:279-311:
     s[i] = prod_j u_j^(+1 if bit (k-1-j)... ) in the reference's doubling order, g and h with the phase separator u on i >= n1,
