@@ -169,17 +169,19 @@ struct VfyTemplateDev {
     const u32* const_c;
     u32 n_const;
 };
-static constexpr u32 VFY_PB_WORDS = 832;  // ztab[32] | yinv_tab[32] | consts[8]: allinv,x,a,b,u,alpha,coefD,- | u_sq[31] | pad
+static constexpr u32 VFY_PB_WORDS = 832;  // ztab[32] | yinv_tab[32] | consts[8]: allinv,x,a,b,u,alpha,alpha*coefD,r*x | u_sq[31] | pad
 static constexpr u32 VFY_PB_SCALARS = VFY_PB_WORDS / 8;
 
-// Per-proof split tables for k_vfy_batch.  With i = hi * 2^LOB + lo:
-//   s[i]       = allinv * prod_{bit j of i set} u_sq[k-1-j]      = s_lo[lo] * s_hi[hi]     (inner_product_proof.rs:302-311 in closed form)
-//   s[N-1-i]   = allinv * prod_{bit j of i clear} u_sq[k-1-j]    = r_lo[lo] * r_hi[hi]
-//   y^-i                                                          = y_lo[lo] * y_hi[hi]
-//   z^e  (e = q + 1 <= Q)                                         = z_lo[e & 255] * z_hi[e >> 8]
-// so the batch kernel pays one product for each of them instead of ~k, ~k/2 and ~lg(Q)/2.  Layout per proof (resident scalars):
-// [s_lo | s_hi | r_lo | r_hi | y_lo | y_hi | z_lo (256) | z_hi (nzhi)], stride 3 * (2^LOB + 2^HIB) + 256 + nzhi.
-// grid (ceil(max(2^LOB, 2^HIB, 256, nzhi) / 256), P).
+// Per-proof split tables for k_vfy_batch.  With i = hi * 2^LOB + lo, and the proof's constants folded into the LOW halves so that the
+// batch kernel gets each weighted quantity with ONE product:
+//   alpha * a * s[i]     (s[i]     = allinv * prod_{bit j of i set} u_sq[k-1-j])    = s_lo[lo] * s_hi[hi]    (inner_product_proof.rs:302-311 in closed form)
+//   b * s[N-1-i]         (s[N-1-i] = allinv * prod_{bit j of i clear} u_sq[k-1-j])  = r_lo[lo] * r_hi[hi]
+//   alpha * x * y^-i                                                                 = yx_lo[lo] * y_hi[hi]
+//   alpha * y^-i                                                                     = ya_lo[lo] * y_hi[hi]
+//   z^e  (e = q + 1 <= Q)                                                            = z_lo[e & 255] * z_hi[e >> 8]
+// Layout per proof (resident scalars): [s_lo | s_hi | r_lo | r_hi | yx_lo | y_hi | ya_lo | z_lo (256) | z_hi (nzhi)],
+// stride vfy_tab_stride() = 3 * (2^LOB + 2^HIB) + 2^LOB + 256 + nzhi.  grid (ceil(max(2^LOB, 2^HIB, 256, nzhi) / 256), P).
+__host__ __device__ inline size_t vfy_tab_stride(u32 nlo, u32 nhi, u32 nzhi) { return (size_t)3 * (nlo + nhi) + nlo + 256 + nzhi; }
 template <class C> __global__ void __launch_bounds__(256)
 k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P, u32 k, u32 LOB, u32 nzhi, u32* __restrict__ tables) {
     typedef typename C::Fr F;
@@ -191,19 +193,23 @@ k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P
     const u32* ytab = pb + 256;
     const u32* cst = pb + 512;
     const u32* usq = pb + 576;
-    u32* T = tables + (size_t)p * (3 * (nlo + nhi) + 256 + nzhi) * 8;
-    u32* Z = T + (size_t)3 * (nlo + nhi) * 8;
+    u32* T = tables + (size_t)p * vfy_tab_stride(nlo, nhi, nzhi) * 8;
+    u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * 8;
     if (tIdx < 256) store_fe_dev<F>(Z + (size_t)tIdx * 8, pow_table<F>(ztab, tIdx));
     if (tIdx < nzhi) store_fe_dev<F>(Z + (size_t)(256 + tIdx) * 8, pow_table<F>(ztab, tIdx << 8));
     if (tIdx < nlo) {
-        Fe s = load_fe_dev<F>(cst), r = s;
+        const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
+        const Fe alpha = load_fe_dev<F>(cst + 40);
+        Fe s = fe_mul<F>(allinv, fe_mul<F>(alpha, a)), r = fe_mul<F>(allinv, b);
         for (u32 j = 0; j < LOB; j++) {
             const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - j) * 8);
             if ((tIdx >> j) & 1) s = fe_mul<F>(s, q); else r = fe_mul<F>(r, q);
         }
         store_fe_dev<F>(T + (size_t)tIdx * 8, s);
         store_fe_dev<F>(T + (size_t)(nlo + nhi + tIdx) * 8, r);
-        store_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + tIdx) * 8, pow_table<F>(ytab, tIdx));
+        const Fe ya = fe_mul<F>(alpha, pow_table<F>(ytab, tIdx));
+        store_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + tIdx) * 8, fe_mul<F>(ya, x));
+        store_fe_dev<F>(T + (size_t)(3 * (nlo + nhi) + tIdx) * 8, ya);
     }
     if (tIdx < nhi) {
         Fe s = fe_one<F>(), r = s;
@@ -231,24 +237,22 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
     if (i < N) {
         for (u32 p = p0; p < p1; p++) {
             const u32* pb = params + (size_t)perm[p] * VFY_PB_WORDS;
-            const u32* ztab = pb;
-            const u32* ytab = pb + 256;
             const u32* cst = pb + 512;
-            const u32* usq = pb + 576;
             // coefficient values: the template's own table, or this proof's (instances of one gadget differ in public constants
             // and in the challenges their randomized constraints carry)
             const u32* coefs = coef_tabs ? coef_tabs + (size_t)p * coef_stride : t.coefs;
-            const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
-            const Fe alpha = load_fe_dev<F>(cst + 40);
+            const Fe x = load_fe_dev<F>(cst + 8), alpha = load_fe_dev<F>(cst + 40);
             const u32 nlo = 1u << LOB, nhi = 1u << (k - LOB), lo = i & (nlo - 1u), hi = i >> LOB;
-            const u32* T = tables + (size_t)p * (3 * (nlo + nhi) + 256 + nzhi) * 8;
-            const u32* Z = T + (size_t)3 * (nlo + nhi) * 8;   // z^e = Z[e & 255] * Z[256 + (e >> 8)]
-            const Fe s_i = fe_mul<F>(load_fe_dev<F>(T + (size_t)lo * 8), load_fe_dev<F>(T + (size_t)(nlo + hi) * 8));
-            const Fe s_rev = fe_mul<F>(load_fe_dev<F>(T + (size_t)(nlo + nhi + lo) * 8), load_fe_dev<F>(T + (size_t)(nlo + nhi + nlo + hi) * 8));
-            const Fe yni = fe_mul<F>(load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + lo) * 8), load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * 8));
-            (void)allinv; (void)usq; (void)ytab;
+            const u32* T = tables + (size_t)p * vfy_tab_stride(nlo, nhi, nzhi) * 8;
+            const u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * 8;   // z^e = Z[e & 255] * Z[256 + (e >> 8)]
+            // the proof's constants ride in the low halves of the split tables (k_vfy_tables): one product each
+            const Fe A = fe_mul<F>(load_fe_dev<F>(T + (size_t)lo * 8), load_fe_dev<F>(T + (size_t)(nlo + hi) * 8));                                  // alpha * a * s[i]
+            const Fe Bv = fe_mul<F>(load_fe_dev<F>(T + (size_t)(nlo + nhi + lo) * 8), load_fe_dev<F>(T + (size_t)(nlo + nhi + nlo + hi) * 8));        // b * s[N-1-i]
+            const Fe yhi = load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * 8);
+            const Fe YA = fe_mul<F>(load_fe_dev<F>(T + (size_t)(3 * (nlo + nhi) + lo) * 8), yhi);                                                    // alpha * y^-i
             Fe g, h;
             if (i < n) {
+                const Fe YX = fe_mul<F>(load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + lo) * 8), yhi);                                                // alpha * x * y^-i
                 // columns i of W_L, W_R, W_O in one pass over their entries sorted by constraint index (equal indices reuse the
                 // power); z^(q+1) is one product of two entries of the proof's split table
                 Fe wL = fe_zero<F>(), wR = fe_zero<F>(), wO = fe_zero<F>(), zp = fe_one<F>();
@@ -264,15 +268,17 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
                     else term = fe_mul<F>(zp, load_fe_dev<F>(coefs + (size_t)cid * 8));
                     if (vec == 0) wL = fe_addr<F>(wL, term); else if (vec == 1) wR = fe_addr<F>(wR, term); else wO = fe_addr<F>(wO, term);
                 }
-                const Fe ywR = fe_mul<F>(yni, wR);
-                g = fe_sub<F, 2>(fe_mul<F>(x, ywR), fe_mul<F>(a, s_i));
+                // alpha * g = alpha*x*y^-i*wR - alpha*a*s[i];  alpha * h = alpha*y^-i * (x*wL + wO - b*s[N-1-i]) - alpha;
+                // alpha*r*x^2 * y^-i*wR*wL = (r*x) * (alpha*x*y^-i*wR) * wL   (verifier.rs:477-500, weighted by the batch's alpha)
+                const Fe Pr = fe_mul<F>(YX, wR);
+                g = fe_sub<F, 2>(Pr, A);
                 Fe tt = fe_addr<F>(fe_mul<F>(x, wL), wO);
-                tt = fe_sub<F, 2>(tt, fe_mul<F>(b, s_rev));
-                h = fe_sub<F, 2>(fe_mul<F>(yni, tt), fe_one<F>());
-                ad = fe_addr<F>(ad, fe_mul<F>(load_fe_dev<F>(cst + 48), fe_mul<F>(ywR, wL)));
+                tt = fe_sub<F, 2>(tt, Bv);
+                h = fe_sub<F, 2>(fe_mul<F>(YA, tt), alpha);
+                ad = fe_addr<F>(ad, fe_mul<F>(load_fe_dev<F>(cst + 56), fe_mul<F>(Pr, wL)));
             } else {
-                g = fe_neg<F, 2>(fe_mul<F>(a, s_i));
-                h = fe_sub<F, 2>(fe_mul<F>(yni, fe_neg<F, 2>(fe_mul<F>(b, s_rev))), fe_one<F>());
+                g = fe_neg<F, 2>(A);
+                h = fe_sub<F, 2>(fe_neg<F, 2>(fe_mul<F>(YA, Bv)), alpha);
             }
             // u_or_1 = 1 for the phase-1 multipliers, u for the randomized-phase ones and on the padding (verifier.rs:486-489)
             if (i >= n1) {
@@ -280,13 +286,14 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
                 g = fe_mul<F>(g, u);
                 h = fe_mul<F>(h, u);
             }
-            ag = fe_addr<F>(ag, fe_mul<F>(alpha, g));
-            ah = fe_addr<F>(ah, fe_mul<F>(alpha, h));
+            ag = fe_addr<F>(ag, g);
+            ah = fe_addr<F>(ah, h);
             // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms
             Fe wcp = fe_zero<F>();
             for (u32 e = i; e < t.n_const; e += N) {   // (lanes share the constant terms; a handful per circuit, or one per gate)
                 const u32 cid = t.const_c[e];
-                const Fe zq = pow_table<F>(ztab, t.const_q[e] + 1);
+                const u32 q1 = t.const_q[e] + 1u;   // (a constant per gate is common: the range-proof gadget has one per bit) - the split table, not a power ladder
+                const Fe zq = fe_mul<F>(load_fe_dev<F>(Z + (size_t)(q1 & 255u) * 8), load_fe_dev<F>(Z + (size_t)(256u + (q1 >> 8)) * 8));
                 Fe term;
                 if (cid & 0x80000000u) term = zq;
                 else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zq));
