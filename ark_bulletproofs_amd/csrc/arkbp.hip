@@ -1771,6 +1771,26 @@ template <class C> static int cs_specify_t(bp_cs* h, bp_randomize_cb cb, void* u
 #define CS_RECORD_GUARD(h) do { if (!cs_live(h)) return BP_E_ARG; if (!CS_DISPATCH(h, cs_can_record<Secq>(h), cs_can_record<Zorro>(h))) { g_err = "this verifier shares its phase-1 constraints (bp_verifier_new_like): only commits and randomized constraints can be added"; return BP_E_ARG; } } while (0)
 
 // ---- C ABI ----------------------------------------------------------------------------------------
+#if defined(__x86_64__)
+template <class C> __attribute__((target("avx512f"))) static void dbg_append_points_x8(void* const* trs, int lanes, const char* label, const uint64_t* xy, size_t npts) {
+    host::StrobeX8 sx;
+    sx.broadcast(((host::Transcript*)trs[0])->s);
+    uint8_t ser[8][72];
+    const uint8_t* ptr[8];
+    for (int l = 0; l < 8; l++) { ptr[l] = ser[l]; memset(ser[l], 0, 72); }
+    for (size_t v = 0; v < npts; v++) {
+        for (int l = 0; l < lanes; l++) {
+            A4 p; memcpy(p.x.v, xy + ((size_t)l * npts + v) * 8, 32); memcpy(p.y.v, xy + ((size_t)l * npts + v) * 8 + 4, 32);
+            host::Grp<C>::ser_uncompressed(ser[l], p);
+        }
+        sx.append_message_each(label, ptr, 65);
+    }
+    host::Strobe* outs[8];
+    for (int l = 0; l < lanes; l++) outs[l] = &((host::Transcript*)trs[l])->s;
+    sx.scatter(outs, lanes);
+}
+#endif
+
 extern "C" {
 
 int bp_device_count(void) {
@@ -2046,6 +2066,16 @@ int bp_transcript_append_point(int curve, void* t, const char* label, const uint
     else if (curve == 1) host::TP<Zorro>::append_point(*(host::Transcript*)t, label, p);
     else return BP_E_ARG;
     return BP_OK;
+}
+int bp_debug_append_points_x8(int curve, void* const* transcripts, int lanes, const char* label, const uint64_t* points_xy, size_t npts) {
+    if (!transcripts || lanes < 2 || lanes > 8 || !label || (npts && !points_xy) || (curve != 0 && curve != 1)) return BP_E_ARG;
+#if defined(__x86_64__)
+    if (!host::cpu_has_avx512()) return BP_E_ARG;
+    if (curve == 0) dbg_append_points_x8<Secq>(transcripts, lanes, label, points_xy, npts); else dbg_append_points_x8<Zorro>(transcripts, lanes, label, points_xy, npts);
+    return BP_OK;
+#else
+    return BP_E_ARG;
+#endif
 }
 int bp_transcript_challenge_scalar(int curve, void* t, const char* label, uint64_t out[4]) {
     F4 r;

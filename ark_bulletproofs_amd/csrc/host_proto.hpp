@@ -255,6 +255,69 @@ __attribute__((target("avx512f"))) static inline void transcript_rng_x8_words(Tr
 }
 #endif
 
+// Eight transcripts driven through the SAME operation sequence (same labels, same message lengths: the verifier transcripts of
+// eight same-shaped statements while their commitments are appended — 74 bytes per point, i.e. ~114 of the ~150 permutations a
+// 256-commitment verification replays).  The sponge states live interleaved (one 64-bit lane of eight AVX-512 registers each); the
+// STROBE positions are shared.  scatter() hands the states back to ordinary Transcripts.
+#if defined(__x86_64__)
+struct StrobeX8 {
+    alignas(64) u64 lanes[25][8];
+    u8 pos = 0, pos_begin = 0, cur = 0;
+    void broadcast(const Strobe& p) {
+        for (int i = 0; i < 25; i++) for (int j = 0; j < 8; j++) lanes[i][j] = p.st.w[i];
+        pos = p.pos; pos_begin = p.pos_begin; cur = p.cur;
+    }
+    void scatter(Strobe* const out[8], int count) const {
+        for (int j = 0; j < count; j++) {
+            for (int i = 0; i < 25; i++) out[j]->st.w[i] = lanes[i][j];
+            out[j]->pos = pos; out[j]->pos_begin = pos_begin; out[j]->cur = cur;
+        }
+    }
+    inline void xor_same(unsigned byte, u8 v) { const u64 x = (u64)v << (8 * (byte & 7)); u64* w = lanes[byte >> 3]; for (int j = 0; j < 8; j++) w[j] ^= x; }
+    __attribute__((target("avx512f"))) void runf() {
+        xor_same(pos, pos_begin); xor_same(pos + 1u, 0x04); xor_same(Strobe::RATE + 1u, 0x80);
+        __m512i st[25];
+        for (int i = 0; i < 25; i++) st[i] = _mm512_load_si512((const void*)lanes[i]);
+        keccakf_x8_avx512(st);
+        for (int i = 0; i < 25; i++) _mm512_store_si512((void*)lanes[i], st[i]);
+        pos = 0; pos_begin = 0;
+    }
+    __attribute__((target("avx512f"))) void absorb_same(const u8* d, size_t n) {
+        for (size_t i = 0; i < n; i++) { xor_same(pos, d[i]); if (++pos == Strobe::RATE) runf(); }
+    }
+    __attribute__((target("avx512f"))) void absorb_each(const u8* const d[8], size_t n) {
+        size_t i = 0;
+        while (i < n) {
+            if ((pos & 7) == 0 && n - i >= 8 && pos + 8 <= Strobe::RATE) {   // a whole 64-bit word of every lane
+                u64* w = lanes[pos >> 3];
+                for (int j = 0; j < 8; j++) { u64 x; memcpy(&x, d[j] + i, 8); w[j] ^= x; }
+                i += 8; pos = (u8)(pos + 8);
+            } else {
+                const unsigned sh = 8 * (pos & 7);
+                u64* w = lanes[pos >> 3];
+                for (int j = 0; j < 8; j++) w[j] ^= (u64)d[j][i] << sh;
+                i++; pos++;
+            }
+            if (pos == Strobe::RATE) runf();
+        }
+    }
+    __attribute__((target("avx512f"))) void begin(u8 flags, bool more) {
+        if (more) return;
+        const u8 hdr[2] = {pos_begin, flags};
+        pos_begin = pos + 1; cur = flags;
+        absorb_same(hdr, 2);
+        if ((flags & (Strobe::fC | Strobe::fK)) && pos != 0) runf();
+    }
+    // Transcript::append_message(label, m_j, n) on all eight
+    __attribute__((target("avx512f"))) void append_message_each(const char* label, const u8* const m[8], size_t n) {
+        const u32 len = (u32)n;
+        begin(Strobe::fM | Strobe::fA, false); absorb_same((const u8*)label, strlen(label));
+        begin(Strobe::fM | Strobe::fA, true); absorb_same((const u8*)&len, 4);
+        begin(Strobe::fA, false); absorb_each(m, n);
+    }
+};
+#endif
+
 // ark-ff Fp::rand: raw limbs (top limb masked to the modulus width) accepted iff < p; they ARE the Montgomery form
 template <class P, class R> static inline F4 rand_fe(R& rng) {
     for (;;) {
@@ -772,19 +835,26 @@ template <class C> static int scenario_verifier(ConstraintSystem<C>& cs, int sc,
 
 // The transcript side of statement construction alone (Verifier::commit appends, plus the scenario's own domain separator):
 // what remains per instance when the constraint matrices come from a cached template.  Only for single-phase scenarios.
-template <class C> static int scenario_verifier_transcript(Transcript& tr, int sc, const u64* prm, const StatementIO& io) {
-    size_t expect = 0;
+// what a scenario's verifier puts into the transcript before its commitments; *expect = the number of commitments it takes
+template <class C> static int scenario_verifier_prefix(Transcript& tr, int sc, const u64* prm, const StatementIO& io, size_t* expect) {
+    *expect = 0;
     switch (sc) {
         case SC_SHUFFLE:   // only k = 1 is single-phase (benches/r1cs_secq256k1.rs:43-46); same prefix as scenario_verifier
-            expect = 2 * prm[0];
+            *expect = 2 * prm[0];
             tr.append_message("dom-sep", "ShuffleProof"); tr.append_u64("k", prm[0]);
             break;
-        case SC_RANGE: expect = 1; break;
-        case SC_EXAMPLE: expect = 5; break;
-        case SC_SQUARE_CHAIN: expect = 1; if (io.publics.size() != 1) return BP_E_ARG; break;
-        case SC_MULTI_RANGE: expect = prm[0]; break;
+        case SC_RANGE: *expect = 1; break;
+        case SC_EXAMPLE: *expect = 5; break;
+        case SC_SQUARE_CHAIN: *expect = 1; if (io.publics.size() != 1) return BP_E_ARG; break;
+        case SC_MULTI_RANGE: *expect = prm[0]; break;
         default: return BP_E_ARG;
     }
+    return BP_OK;
+}
+template <class C> static int scenario_verifier_transcript(Transcript& tr, int sc, const u64* prm, const StatementIO& io) {
+    size_t expect = 0;
+    const int rc = scenario_verifier_prefix<C>(tr, sc, prm, io, &expect);
+    if (rc) return rc;
     if (io.commitments.size() != expect) return BP_E_ARG;
     for (auto& Vp : io.commitments) TP<C>::append_point(tr, "V", Vp);
     return BP_OK;

@@ -353,6 +353,18 @@ def debug_rng_draws(curve, transcript, witness, seeds, count):
     return out
 
 
+def debug_append_points_x8(curve, transcripts, label, points):
+    """points: (lanes, npts, 8) u64; appends them to the HostTranscripts in lockstep (AVX-512 Keccak-f x8); False if unavailable"""
+    pts = np.ascontiguousarray(points, dtype=np.uint64)
+    lanes, npts = pts.shape[0], pts.shape[1]
+    arr = (C.c_void_p * lanes)(*[t.h for t in transcripts])
+    rc = lib().bp_debug_append_points_x8(curve, arr, lanes, bytes(label), ptr(pts), C.c_size_t(npts))
+    if rc == _lib.BP_E_ARG:
+        return False
+    check(rc, "bp_debug_append_points_x8")
+    return True
+
+
 def pedersen_gens(curve):
     B, Bb = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
     check(lib().bp_pedersen_gens(curve, ptr(B), ptr(Bb)), "bp_pedersen_gens")

@@ -177,6 +177,11 @@ int bp_host_sha3_512(const uint8_t* msg, size_t n, uint8_t out[64]);
  * path (one 32-byte seed), lanes = 8 the AVX-512 x8 stream (8 seeds; out = 8 x count scalars; BP_E_ARG if unavailable) */
 int bp_debug_rng_draws(int curve, void* transcript, const uint64_t* witness, size_t nw, const uint8_t* seeds, int lanes, size_t count,
                        uint64_t* out);
+/* Test hook of the lockstep transcript path of batch verification (host::StrobeX8; the eight verifier transcripts of a group take
+ * their commitments through AVX-512 Keccak-f x8): appends `npts` points under `label` to each of the `lanes` (2..8) transcripts, which
+ * must all be in the state of transcripts[0]; points_xy = [lane][npts][8].  The result must equal bp_transcript_append_point applied
+ * lane by lane.  BP_E_ARG when the host has no AVX-512 (the product then takes the scalar path). */
+int bp_debug_append_points_x8(int curve, void* const* transcripts, int lanes, const char* label, const uint64_t* points_xy, size_t npts);
 /* group sum of affine points on the host (the point-reduce after an all-gather of per-GPU partials) */
 int bp_host_points_sum(int curve, const uint64_t* pts_xy, size_t count, uint64_t out_xy[8]);
 

@@ -84,6 +84,33 @@ def test_product_transcript_rng_scalar_and_x8(E, oracle, curve):
     assert (got8 == exp).all()
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("lanes,npts,prefix", [(8, 256, 0), (8, 5, 3), (3, 40, 77), (2, 1, 165)])
+def test_product_lockstep_commitment_appends_equal_scalar_appends(E, oracle, curve, lanes, npts, prefix):
+    """batch verification appends the commitments of eight same-shaped instances in lockstep (host::StrobeX8): every transcript
+    must end in exactly the state the one-at-a-time appends leave (checked through a challenge and further use), for any STROBE
+    position the prefix leaves (here 0 .. 165 of the 166-byte rate)."""
+    O = oracle
+    G, H = O.bp_gens(curve, max(npts, 2) * 4)
+    pool = np.concatenate([G, H, np.zeros((1, 8), dtype=np.uint64)])   # (the identity serialises differently: flag 0x40)
+    pts = np.stack([[pool[(l * 31 + v * 7 + (v * v) % 5) % len(pool)] for v in range(npts)] for l in range(lanes)])
+    a = [E.HostTranscript(b"lockstep") for _ in range(lanes)]
+    b = [E.HostTranscript(b"lockstep") for _ in range(lanes)]
+    for t in a + b:
+        t.append_message(b"pad", bytes(range(prefix % 256)) * 1 if prefix else b"")
+    if not E.debug_append_points_x8(curve, a, b"V", pts):
+        pytest.skip("no AVX-512 on this host: the product takes the scalar path")
+    for l in range(lanes):
+        for v in range(npts):
+            b[l].append_point(curve, b"V", pts[l, v])
+    for l in range(lanes):
+        assert a[l].challenge_bytes(b"c", 64) == b[l].challenge_bytes(b"c", 64)
+        a[l].append_message(b"more", b"x" * 200)
+        b[l].append_message(b"more", b"x" * 200)
+        assert a[l].challenge_bytes(b"d", 16) == b[l].challenge_bytes(b"d", 16)
+    assert len({a[l].challenge_bytes(b"e", 8) for l in range(lanes)}) == lanes or npts == 0
+
+
 def test_product_glv_decomposition():
     """Host-side GLV split used by the uniform IPA fold on secq256k1: t = t1 + lambda*t2 (mod r), both halves given as
     non-adjacent signed digits of at most 130 positions; lambda is a primitive cube root of unity in Fr."""
