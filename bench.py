@@ -531,8 +531,9 @@ def run_verify(args, rank, world, local):
         e2.share_gens_from(eng)
         engs.append(e2)
     if nfl > 1 and not os.environ.get("ARKBP_HOST_THREADS"):
-        # several pools share the cores this process may use (measured on a 16-CPU cgroup: 2 x 12 threads 177 K proofs/s, 2 x 24 168 K,
-        # 2 x 8 151 K, 1 x 32 162 K)
+        # several pools share the cores this process may use (measured on a 16-CPU cgroup, one session: 1 x 32 threads 215 K proofs/s,
+        # 2 x 12 250 K, 3 x 8 255-263 K, 3 x 10 270 K, 4 x 6 274 K, 4 x 8 252 K — a plateau; before the pools divided the cores two
+        # batches in flight were no faster than one)
         per_pool = max(4, int(round(cpu_quota() * 1.5 / nfl)))
         for e in engs:
             e.set_tuning(6, per_pool)   # BP_TUNE_HOST_THREADS
@@ -660,7 +661,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
-    ap.add_argument("--verify-inflight", type=int, default=2, help="verify workload: batch_verify calls in flight per GPU (own ctx and host pool each; the pools divide the process's CPU quota)")
+    ap.add_argument("--verify-inflight", type=int, default=3, help="verify workload: batch_verify calls in flight per GPU (own ctx and host pool each; the pools divide the process's CPU quota)")
     ap.add_argument("--shuffle-k", type=int, default=0, help="verify workload: batches of k-shuffle proofs (the reference's two-phase benchmark circuit) instead of cfg4's range proofs")
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")

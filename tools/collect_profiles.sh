@@ -22,7 +22,7 @@ pmc() {     # pmc TAG -- cmd...
 }
 stats prove_single -- python3 $R/tools/one_proof.py 20 2
 stats bench_default -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline
-stats verify -- python3 $R/bench.py --workload verify --steps 5 --warmup 1 --no-cpu-baseline
+stats verify -- python3 $R/bench.py --workload verify --steps 5 --warmup 1 --verify-inflight 1 --no-cpu-baseline   # (one batch at a time: kernel durations as bench.py reports them, from a batch run alone)
 stats msm_2p16 -- python3 $R/bench.py --workload msm --terms 65536 --steps 20 --warmup 3 --no-cpu-baseline
 stats msm_2p20 -- python3 $R/bench.py --workload msm --terms 1048576 --steps 10 --warmup 3 --no-cpu-baseline
 pmc prove2p20 -- python3 $R/tools/one_proof.py 20 1
