@@ -172,6 +172,22 @@ struct VfyTemplateDev {
 static constexpr u32 VFY_PB_WORDS = 832;  // ztab[32] | yinv_tab[32] | consts[8]: allinv,x,a,b,u,alpha,alpha*coefD,r*x | u_sq[31] | pad
 static constexpr u32 VFY_PB_SCALARS = VFY_PB_WORDS / 8;
 
+// Entries of the per-proof split tables are kept as their nine 29-bit limbs (12 words each, 16-byte aligned): k_vfy_batch reads ~20
+// of them per (proof, element) and the packed form costs ~25 unpack instructions per read
+static constexpr u32 VT_W = 12;
+__device__ __forceinline__ void store_fe_limbs(u32* __restrict__ p, const Fe& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
+    q[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
+    p[8] = a.l[8];
+}
+__device__ __forceinline__ Fe load_fe_limbs(const u32* __restrict__ p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1];
+    Fe r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = p[8];
+    return r;
+}
 // Per-proof split tables for k_vfy_batch.  With i = hi * 2^LOB + lo, and the proof's constants folded into the LOW halves so that the
 // batch kernel gets each weighted quantity with ONE product:
 //   alpha * a * s[i]     (s[i]     = allinv * prod_{bit j of i set} u_sq[k-1-j])    = s_lo[lo] * s_hi[hi]    (inner_product_proof.rs:302-311 in closed form)
@@ -179,7 +195,7 @@ static constexpr u32 VFY_PB_SCALARS = VFY_PB_WORDS / 8;
 //   alpha * x * y^-i                                                                 = yx_lo[lo] * y_hi[hi]
 //   alpha * y^-i                                                                     = ya_lo[lo] * y_hi[hi]
 //   z^e  (e = q + 1 <= Q)                                                            = z_lo[e & 255] * z_hi[e >> 8]
-// Layout per proof (resident scalars): [s_lo | s_hi | r_lo | r_hi | yx_lo | y_hi | ya_lo | z_lo (256) | z_hi (nzhi)],
+// Layout per proof (entries of VT_W words: the nine limbs of a product, i.e. < 1.04 p): [s_lo | s_hi | r_lo | r_hi | yx_lo | y_hi | ya_lo | z_lo (256) | z_hi (nzhi)],
 // stride vfy_tab_stride() = 3 * (2^LOB + 2^HIB) + 2^LOB + 256 + nzhi.  grid (ceil(max(2^LOB, 2^HIB, 256, nzhi) / 256), P).
 __host__ __device__ inline size_t vfy_tab_stride(u32 nlo, u32 nhi, u32 nzhi) { return (size_t)3 * (nlo + nhi) + nlo + 256 + nzhi; }
 template <class C> __global__ void __launch_bounds__(256)
@@ -193,10 +209,10 @@ k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P
     const u32* ytab = pb + 256;
     const u32* cst = pb + 512;
     const u32* usq = pb + 576;
-    u32* T = tables + (size_t)p * vfy_tab_stride(nlo, nhi, nzhi) * 8;
-    u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * 8;
-    if (tIdx < 256) store_fe_dev<F>(Z + (size_t)tIdx * 8, pow_table<F>(ztab, tIdx));
-    if (tIdx < nzhi) store_fe_dev<F>(Z + (size_t)(256 + tIdx) * 8, pow_table<F>(ztab, tIdx << 8));
+    u32* T = tables + (size_t)p * vfy_tab_stride(nlo, nhi, nzhi) * VT_W;
+    u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * VT_W;
+    if (tIdx < 256) store_fe_limbs(Z + (size_t)tIdx * VT_W, pow_table<F>(ztab, tIdx));
+    if (tIdx < nzhi) store_fe_limbs(Z + (size_t)(256 + tIdx) * VT_W, pow_table<F>(ztab, tIdx << 8));
     if (tIdx < nlo) {
         const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
         const Fe alpha = load_fe_dev<F>(cst + 40);
@@ -205,11 +221,11 @@ k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P
             const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - j) * 8);
             if ((tIdx >> j) & 1) s = fe_mul<F>(s, q); else r = fe_mul<F>(r, q);
         }
-        store_fe_dev<F>(T + (size_t)tIdx * 8, s);
-        store_fe_dev<F>(T + (size_t)(nlo + nhi + tIdx) * 8, r);
+        store_fe_limbs(T + (size_t)tIdx * VT_W, s);
+        store_fe_limbs(T + (size_t)(nlo + nhi + tIdx) * VT_W, r);
         const Fe ya = fe_mul<F>(alpha, pow_table<F>(ytab, tIdx));
-        store_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + tIdx) * 8, fe_mul<F>(ya, x));
-        store_fe_dev<F>(T + (size_t)(3 * (nlo + nhi) + tIdx) * 8, ya);
+        store_fe_limbs(T + (size_t)(2 * (nlo + nhi) + tIdx) * VT_W, fe_mul<F>(ya, x));
+        store_fe_limbs(T + (size_t)(3 * (nlo + nhi) + tIdx) * VT_W, ya);
     }
     if (tIdx < nhi) {
         Fe s = fe_one<F>(), r = s;
@@ -217,9 +233,9 @@ k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P
             const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - (LOB + j)) * 8);
             if ((tIdx >> j) & 1) s = fe_mul<F>(s, q); else r = fe_mul<F>(r, q);
         }
-        store_fe_dev<F>(T + (size_t)(nlo + tIdx) * 8, s);
-        store_fe_dev<F>(T + (size_t)(nlo + nhi + nlo + tIdx) * 8, r);
-        store_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + nlo + tIdx) * 8, pow_table<F>(ytab, tIdx << LOB));
+        store_fe_limbs(T + (size_t)(nlo + tIdx) * VT_W, s);
+        store_fe_limbs(T + (size_t)(nlo + nhi + nlo + tIdx) * VT_W, r);
+        store_fe_limbs(T + (size_t)(2 * (nlo + nhi) + nlo + tIdx) * VT_W, pow_table<F>(ytab, tIdx << LOB));
     }
 }
 
@@ -243,23 +259,23 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
             const u32* coefs = coef_tabs ? coef_tabs + (size_t)p * coef_stride : t.coefs;
             const Fe x = load_fe_dev<F>(cst + 8), alpha = load_fe_dev<F>(cst + 40);
             const u32 nlo = 1u << LOB, nhi = 1u << (k - LOB), lo = i & (nlo - 1u), hi = i >> LOB;
-            const u32* T = tables + (size_t)p * vfy_tab_stride(nlo, nhi, nzhi) * 8;
-            const u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * 8;   // z^e = Z[e & 255] * Z[256 + (e >> 8)]
+            const u32* T = tables + (size_t)p * vfy_tab_stride(nlo, nhi, nzhi) * VT_W;
+            const u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * VT_W;   // z^e = Z[e & 255] * Z[256 + (e >> 8)]
             // the proof's constants ride in the low halves of the split tables (k_vfy_tables): one product each
-            const Fe A = fe_mul<F>(load_fe_dev<F>(T + (size_t)lo * 8), load_fe_dev<F>(T + (size_t)(nlo + hi) * 8));                                  // alpha * a * s[i]
-            const Fe Bv = fe_mul<F>(load_fe_dev<F>(T + (size_t)(nlo + nhi + lo) * 8), load_fe_dev<F>(T + (size_t)(nlo + nhi + nlo + hi) * 8));        // b * s[N-1-i]
-            const Fe yhi = load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * 8);
-            const Fe YA = fe_mul<F>(load_fe_dev<F>(T + (size_t)(3 * (nlo + nhi) + lo) * 8), yhi);                                                    // alpha * y^-i
+            const Fe A = fe_mul<F>(load_fe_limbs(T + (size_t)lo * VT_W), load_fe_limbs(T + (size_t)(nlo + hi) * VT_W));                                  // alpha * a * s[i]
+            const Fe Bv = fe_mul<F>(load_fe_limbs(T + (size_t)(nlo + nhi + lo) * VT_W), load_fe_limbs(T + (size_t)(nlo + nhi + nlo + hi) * VT_W));        // b * s[N-1-i]
+            const Fe yhi = load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * VT_W);
+            const Fe YA = fe_mul<F>(load_fe_limbs(T + (size_t)(3 * (nlo + nhi) + lo) * VT_W), yhi);                                                    // alpha * y^-i
             Fe g, h;
             if (i < n) {
-                const Fe YX = fe_mul<F>(load_fe_dev<F>(T + (size_t)(2 * (nlo + nhi) + lo) * 8), yhi);                                                // alpha * x * y^-i
+                const Fe YX = fe_mul<F>(load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + lo) * VT_W), yhi);                                                // alpha * x * y^-i
                 // columns i of W_L, W_R, W_O in one pass over their entries sorted by constraint index (equal indices reuse the
                 // power); z^(q+1) is one product of two entries of the proof's split table
                 Fe wL = fe_zero<F>(), wR = fe_zero<F>(), wO = fe_zero<F>(), zp = fe_one<F>();
                 u32 cur = 0;   // exponent zp holds (0 = none yet; q + 1 >= 1 always)
                 for (u32 e = t.m_off[i], e1 = t.m_off[i + 1]; e < e1; e++) {
                     const u32 ent = t.m_ent[e], q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
-                    if (q1 != cur) zp = fe_mul<F>(load_fe_dev<F>(Z + (size_t)(q1 & 255u) * 8), load_fe_dev<F>(Z + (size_t)(256u + (q1 >> 8)) * 8));
+                    if (q1 != cur) zp = fe_mul<F>(load_fe_limbs(Z + (size_t)(q1 & 255u) * VT_W), load_fe_limbs(Z + (size_t)(256u + (q1 >> 8)) * VT_W));
                     cur = q1;
                     const u32 cid = t.m_c[e];   // bit 31: the coefficient is +1, bit 30: it is -1 (most gadget constraints): no product
                     Fe term;
@@ -293,7 +309,7 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
             for (u32 e = i; e < t.n_const; e += N) {   // (lanes share the constant terms; a handful per circuit, or one per gate)
                 const u32 cid = t.const_c[e];
                 const u32 q1 = t.const_q[e] + 1u;   // (a constant per gate is common: the range-proof gadget has one per bit) - the split table, not a power ladder
-                const Fe zq = fe_mul<F>(load_fe_dev<F>(Z + (size_t)(q1 & 255u) * 8), load_fe_dev<F>(Z + (size_t)(256u + (q1 >> 8)) * 8));
+                const Fe zq = fe_mul<F>(load_fe_limbs(Z + (size_t)(q1 & 255u) * VT_W), load_fe_limbs(Z + (size_t)(256u + (q1 >> 8)) * VT_W));
                 Fe term;
                 if (cid & 0x80000000u) term = zq;
                 else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zq));
