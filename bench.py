@@ -11,7 +11,8 @@ and cpu_baseline.  The reference's own benchmark workload is benches/r1cs_secq25
 A "step" is one pass of the hot path over one batch of synthetic input.  `--gpus N` with N > 1 and no WORLD_SIZE in the
 environment starts N ranks itself (torch.distributed.run, one process per GPU, before this process touches the GPU); under a
 launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  Units are sharded across ranks (weak scaling); the only exchange is the
-all-gather of one 64-byte partial point per rank.
+all-gather of one 64-byte partial point (and a status word) per rank and step — in the verify workload, where several batches are
+in flight per GPU, gathered for all steps at once at the end of the timed region.
 
 Documented multi-GPU commands (SCALE): `bench.py --gpus N` (prove replicas + proof-sharded verify),
 `bench.py --gpus N --workload verify`, `bench.py --gpus N --workload prove --shard windows --logn 22` (cfg5: one proof at a
@@ -524,17 +525,17 @@ def run_verify(args, rank, world, local):
     # `--verify-inflight` batches in flight per GPU (like the prover's proofs in flight): each on its own ctx / stream with its own
     # host pool, sharing the resident generator tables.  One batch alone leaves the GPU idle while the host parses and replays the
     # first block and the host idle during the drain and the final MSM; a second batch fills those.
-    nfl = max(1, args.verify_inflight) if world == 1 else 1      # (sharded runs exchange a point per step: one batch at a time)
+    nfl = max(1, args.verify_inflight)
     engs = [eng]
     for _ in range(nfl - 1):
         e2 = A.Engine(curve=args.curve, device=local)
         e2.share_gens_from(eng)
         engs.append(e2)
-    if nfl > 1 and not os.environ.get("ARKBP_HOST_THREADS"):
+    if (nfl > 1 or world > 1) and not os.environ.get("ARKBP_HOST_THREADS"):
         # several pools share the cores this process may use (measured on a 16-CPU cgroup, one session: 1 x 32 threads 215 K proofs/s,
         # 2 x 12 250 K, 3 x 8 255-263 K, 3 x 10 270 K, 4 x 6 274 K, 4 x 8 252 K — a plateau; before the pools divided the cores two
         # batches in flight were no faster than one)
-        per_pool = max(4, int(round(cpu_quota() * 1.5 / nfl)))
+        per_pool = max(4, int(round(cpu_quota() / world * 1.5 / nfl)))   # (the ranks of a node share its quota)
         for e in engs:
             e.set_tuning(6, per_pool)   # BP_TUNE_HOST_THREADS
     for _ in range(args.warmup):
@@ -544,29 +545,31 @@ def run_verify(args, rank, world, local):
     t0 = time.perf_counter()
     tms = np.zeros(5)
     ok = True
-    if nfl == 1:
-        for _ in range(args.steps):
-            rc, tm, pt = eng.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
-            parts = P.allgather_points(pt, device=COLL_DEVICE if world > 1 else None)
-            ok = ok and rc == 0 and not E.host_points_sum(args.curve, parts).any()
-            tms += np.array(tm)
-    else:
-        nxt, lock, oks, tml = [0], threading.Lock(), [], []
+    # every rank verifies its shard of every step's batch (its own alphas through alpha_skip), `nfl` calls in flight; the ranks'
+    # statuses and check points of ALL steps are exchanged in one all-gather at the end of the timed region (a 64-byte point per rank
+    # and step: the exchange is not on any step's critical path) and each step is judged as parallel.sharded_batch_verify does:
+    # valid iff every rank's status is 0, the sum of the points is the identity as a consistency check
+    step_pts = np.zeros((args.steps, 9), dtype=np.uint64)
+    nxt, lock, tml = [0], threading.Lock(), []
 
-        def worker(e):
-            while True:
-                with lock:
-                    i = nxt[0]
-                    nxt[0] += 1
-                if i >= args.steps:
-                    return
-                rc, tm, pt = e.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
-                oks.append(rc == 0 and not pt.any())
-                tml.append(tm)
+    def worker(e):
+        while True:
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= args.steps:
+                return
+            rc, tm, pt = e.batch_verify(inst, seed, alpha_skip=lo, want_point=True)
+            step_pts[i, :8] = pt
+            step_pts[i, 8] = 0 if rc == 0 else 1
+            tml.append(tm)
 
-        run_threads([(worker, (e,)) for e in engs])
-        ok = all(oks) and len(oks) == args.steps
-        tms = np.sum(np.array(tml), axis=0)
+    run_threads([(worker, (e,)) for e in engs])
+    allp = P.allgather_words(step_pts, device=COLL_DEVICE if world > 1 else None)      # (world, steps, 9)
+    for i in range(args.steps):
+        ok = ok and not allp[:, i, 8].any() and not E.host_points_sum(args.curve, np.ascontiguousarray(allp[:, i, :8])).any()
+    ok = ok and len(tml) == args.steps
+    tms = np.sum(np.array(tml), axis=0)
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     assert ok, "batch verification of valid proofs failed"
