@@ -195,9 +195,10 @@ __device__ __forceinline__ Fe load_fe_limbs(const u32* __restrict__ p) {
 //   alpha * x * y^-i                                                                 = yx_lo[lo] * y_hi[hi]
 //   alpha * y^-i                                                                     = ya_lo[lo] * y_hi[hi]
 //   z^e  (e = q + 1 <= Q)                                                            = z_lo[e & 255] * z_hi[e >> 8]
-// Layout per proof (entries of VT_W words: the nine limbs of a product, i.e. < 1.04 p): [s_lo | s_hi | r_lo | r_hi | yx_lo | y_hi | ya_lo | z_lo (256) | z_hi (nzhi)],
-// stride vfy_tab_stride() = 3 * (2^LOB + 2^HIB) + 2^LOB + 256 + nzhi.  grid (ceil(max(2^LOB, 2^HIB, 256, nzhi) / 256), P).
-__host__ __device__ inline size_t vfy_tab_stride(u32 nlo, u32 nhi, u32 nzhi) { return (size_t)3 * (nlo + nhi) + nlo + 256 + nzhi; }
+//   alpha * x * z^e  (the constant terms, whose weight alpha*r*x^2 is (r*x) times this)  = zx_lo[e & 255] * z_hi[e >> 8]
+// Layout per proof (entries of VT_W words: the nine limbs of a product, i.e. < 1.04 p): [s_lo | s_hi | r_lo | r_hi | yx_lo | y_hi | ya_lo | z_lo (256) | z_hi (nzhi) | zx_lo (256)],
+// stride vfy_tab_stride() = 3 * (2^LOB + 2^HIB) + 2^LOB + 512 + nzhi.  grid (ceil(max(2^LOB, 2^HIB, 256, nzhi) / 256), P).
+__host__ __device__ inline size_t vfy_tab_stride(u32 nlo, u32 nhi, u32 nzhi) { return (size_t)3 * (nlo + nhi) + nlo + 256 + nzhi + 256; }
 template <class C> __global__ void __launch_bounds__(256)
 k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P, u32 k, u32 LOB, u32 nzhi, u32* __restrict__ tables) {
     typedef typename C::Fr F;
@@ -211,7 +212,11 @@ k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P
     const u32* usq = pb + 576;
     u32* T = tables + (size_t)p * vfy_tab_stride(nlo, nhi, nzhi) * VT_W;
     u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * VT_W;
-    if (tIdx < 256) store_fe_limbs(Z + (size_t)tIdx * VT_W, pow_table<F>(ztab, tIdx));
+    if (tIdx < 256) {
+        const Fe zp = pow_table<F>(ztab, tIdx);
+        store_fe_limbs(Z + (size_t)tIdx * VT_W, zp);
+        store_fe_limbs(Z + (size_t)(256 + nzhi + tIdx) * VT_W, fe_mul<F>(fe_mul<F>(load_fe_dev<F>(cst + 40), load_fe_dev<F>(cst + 8)), zp));
+    }
     if (tIdx < nzhi) store_fe_limbs(Z + (size_t)(256 + tIdx) * VT_W, pow_table<F>(ztab, tIdx << 8));
     if (tIdx < nlo) {
         const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
@@ -266,7 +271,7 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
             const Fe Bv = fe_mul<F>(load_fe_limbs(T + (size_t)(nlo + nhi + lo) * VT_W), load_fe_limbs(T + (size_t)(nlo + nhi + nlo + hi) * VT_W));        // b * s[N-1-i]
             const Fe yhi = load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * VT_W);
             const Fe YA = fe_mul<F>(load_fe_limbs(T + (size_t)(3 * (nlo + nhi) + lo) * VT_W), yhi);                                                    // alpha * y^-i
-            Fe g, h;
+            Fe g, h, dl = fe_zero<F>();
             if (i < n) {
                 const Fe YX = fe_mul<F>(load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + lo) * VT_W), yhi);                                                // alpha * x * y^-i
                 // columns i of W_L, W_R, W_O in one pass over their entries sorted by constraint index (equal indices reuse the
@@ -291,7 +296,7 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
                 Fe tt = fe_addr<F>(fe_mul<F>(x, wL), wO);
                 tt = fe_sub<F, 2>(tt, Bv);
                 h = fe_sub<F, 2>(fe_mul<F>(YA, tt), alpha);
-                ad = fe_addr<F>(ad, fe_mul<F>(load_fe_dev<F>(cst + 56), fe_mul<F>(Pr, wL)));
+                dl = fe_mul<F>(Pr, wL);
             } else {
                 g = fe_neg<F, 2>(A);
                 h = fe_sub<F, 2>(fe_neg<F, 2>(fe_mul<F>(YA, Bv)), alpha);
@@ -304,19 +309,27 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
             }
             ag = fe_addr<F>(ag, g);
             ah = fe_addr<F>(ah, h);
-            // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms
+            // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms;
+            // wcp collects alpha * x * (their sum)
             Fe wcp = fe_zero<F>();
             for (u32 e = i; e < t.n_const; e += N) {   // (lanes share the constant terms; a handful per circuit, or one per gate)
                 const u32 cid = t.const_c[e];
                 const u32 q1 = t.const_q[e] + 1u;   // (a constant per gate is common: the range-proof gadget has one per bit) - the split table, not a power ladder
-                const Fe zq = fe_mul<F>(load_fe_limbs(Z + (size_t)(q1 & 255u) * VT_W), load_fe_limbs(Z + (size_t)(256u + (q1 >> 8)) * VT_W));
+                const Fe zq = fe_mul<F>(load_fe_limbs(Z + (size_t)(256u + nzhi + (q1 & 255u)) * VT_W), load_fe_limbs(Z + (size_t)(256u + (q1 >> 8)) * VT_W));   // alpha * x * z^(q+1)
                 Fe term;
                 if (cid & 0x80000000u) term = zq;
                 else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zq));
                 else term = fe_mul<F>(zq, load_fe_dev<F>(coefs + (size_t)cid * 8));
                 wcp = fe_addr<F>(wcp, term);
             }
-            if (t.n_const > i) ad = fe_addr<F>(ad, fe_neg<F, 4>(fe_mul<F>(load_fe_dev<F>(cst + 48), wcp)));
+            // alpha*r*x^2 * (y^-i*wR*wL - wc terms) = (r*x) * (alpha*x*y^-i*wR*wL - alpha*x*wc): one product for both
+            if (i < n || t.n_const > i) {
+                Fe tsum;
+                if (i < n && t.n_const > i) tsum = fe_sub<F, 4>(dl, wcp);
+                else if (i < n) tsum = dl;
+                else tsum = fe_neg<F, 4>(wcp);
+                ad = fe_addr<F>(ad, fe_mul<F>(load_fe_dev<F>(cst + 56), tsum));
+            }
         }
         store_fe_dev<F>(g_part + ((size_t)chunk * N + i) * 8, ag);
         store_fe_dev<F>(h_part + ((size_t)chunk * N + i) * 8, ah);
