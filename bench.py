@@ -535,7 +535,7 @@ def run_verify(args, rank, world, local):
         # several pools share the cores this process may use (measured on a 16-CPU cgroup, one session: 1 x 32 threads 215 K proofs/s,
         # 2 x 12 250 K, 3 x 8 255-263 K, 3 x 10 270 K, 4 x 6 274 K, 4 x 8 252 K — a plateau; before the pools divided the cores two
         # batches in flight were no faster than one)
-        per_pool = max(4, int(round(cpu_quota() / world * 1.5 / nfl)))   # (the ranks of a node share its quota)
+        per_pool = min(32, max(4, int(round(cpu_quota() / world * 1.5 / nfl))))   # (the ranks of a node share its quota)
         for e in engs:
             e.set_tuning(6, per_pool)   # BP_TUNE_HOST_THREADS
     for _ in range(args.warmup):
