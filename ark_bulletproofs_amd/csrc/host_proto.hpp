@@ -436,18 +436,24 @@ static inline const char* scenario_label(int sc) {
 // same id sequence — hence the same 128-bit structure digest — and a small per-instance table id -> value.  The GPU-resident
 // constraint matrices ("templates", r1cs_host.inc) are keyed by the digest and evaluated with the instance's table.
 static constexpr u32 CID_ONE = 0x80000000u, CID_MONE = 0x40000000u, CID_MASK = 0x3fffffffu;
+// The key of a circuit template: two multiply/xorshift lanes over the canonical stream, a third, independently built fingerprint
+// (position-weighted sum through a splitmix64 finaliser: not a function of the first two lanes' states) and the exact number of
+// mixed words — four 64-bit quantities compared on every template lookup, on top of the (n, n1, q, ncoef) check there.
 struct Digest {
-    u64 a = 0, b = 0;
-    bool operator==(const Digest& o) const { return a == o.a && b == o.b; }
-    bool operator<(const Digest& o) const { return a != o.a ? a < o.a : b < o.b; }
+    u64 a = 0, b = 0, c = 0, cnt = 0;
+    bool operator==(const Digest& o) const { return a == o.a && b == o.b && c == o.c && cnt == o.cnt; }
+    bool operator<(const Digest& o) const { return a != o.a ? a < o.a : b != o.b ? b < o.b : c != o.c ? c < o.c : cnt < o.cnt; }
 };
 struct CanonState {
-    u64 ha = 0x9E3779B97F4A7C15ULL, hb = 0xC2B2AE3D27D4EB4FULL;
+    u64 ha = 0x9E3779B97F4A7C15ULL, hb = 0xC2B2AE3D27D4EB4FULL, hc = 0, cnt = 0;
     std::vector<F4> coefs;      // id -> value
     std::vector<u32> slots;     // open addressing over coefs (power-of-two size, 0xFFFFFFFF = empty)
     inline void mix(u64 x) {
         ha = (ha ^ x) * 0xFF51AFD7ED558CCDULL; ha ^= ha >> 32;
         hb = (hb + x) * 0x9FB21C651E98DF25ULL; hb = (hb << 27) | (hb >> 37);
+        u64 z = x + (++cnt) * 0x9E3779B97F4A7C15ULL;   // splitmix64 of (word, position), summed: order-sensitive through the position
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        hc += z ^ (z >> 31);
     }
     static inline u64 hash_fe(const F4& c) { u64 h = c.v[0] * 0x9E3779B97F4A7C15ULL ^ c.v[1] * 0xC2B2AE3D27D4EB4FULL ^ c.v[2] * 0x165667B19E3779F9ULL ^ c.v[3]; return h ^ (h >> 29); }
     void grow() {
@@ -478,7 +484,12 @@ struct CanonState {
             }
         }
     }
-    Digest digest(size_t n1, size_t n, size_t nq) const { CanonState t; t.ha = ha; t.hb = hb; t.mix(n1); t.mix(n); t.mix(nq); t.mix(coefs.size()); Digest d; d.a = t.ha; d.b = t.hb; return d; }
+    Digest digest(size_t n1, size_t n, size_t nq) const {
+        CanonState t; t.ha = ha; t.hb = hb; t.hc = hc; t.cnt = cnt;
+        t.mix(n1); t.mix(n); t.mix(nq); t.mix(coefs.size());
+        Digest d; d.a = t.ha; d.b = t.hb; d.c = t.hc; d.cnt = t.cnt;
+        return d;
+    }
 };
 struct VTerm { u32 j, q; F4 c; };   // committed variable j in constraint q with coefficient c: feeds wV (verifier.rs:334-338, prover.rs:385-387)
 

@@ -482,6 +482,59 @@ k_ftab_normalize(const u32* __restrict__ tmp, u32* __restrict__ pref, u32* __res
         store_words8(out + ((size_t)e * n + i) * 16 + 8, w + 8);
     }
 }
+// ---- integrity check of the precomputed tables (bp_gens_tables_check) ---------------------------------------------------------
+// The tables are up to ~150 GB of HBM that only ever enter a proof a few rows at a time (the rows a round's digits select), so a
+// wrong entry would surface as one rare bad proof.  The check walks EVERY entry through the chain rule the builder used, with
+// different formulas (mixed addition / doubling of the stored AFFINE neighbours, compared projectively: no inversion), anchored
+// at the generator itself:   T[0][0][i] = G[i],  T[j][e][i] = T[j][e-1][i] + T[j][0][i],  T[j+1][0][i] = 2 * T[j][E-1][i].
+// Jacobian J equals affine A ?  (X == x*Z^2, Y == y*Z^3; identity <-> identity)
+template <class C> __device__ __forceinline__ bool jac_equals_aff(const Jac& J, const Aff& A) {
+    typedef typename C::Fq F;
+    const bool ji = jac_is_inf(J), ai = aff_is_inf(A);
+    if (ji || ai) return ji && ai;
+    const Fe zz = fe_sqr<F>(J.Z);
+    if (!fe_eq_mod<F>(fe_wred<F>(J.X), fe_mul<F>(A.x, zz))) return false;
+    return fe_eq_mod<F>(fe_wred<F>(J.Y), fe_mul<F>(A.y, fe_mul<F>(zz, J.Z)));
+}
+template <class C> __global__ void __launch_bounds__(256)
+k_ftab_check(const u32* __restrict__ gens, const u32* __restrict__ T, u32 n, u32 E, u32 nwin, unsigned long long* __restrict__ bad) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 wrong = 0;
+    Aff first = load_aff_dev(gens + (size_t)i * 16);      // what T[j][0][i] must equal (j = 0), then only its Jacobian successor
+    Jac expect = jac_from_aff<C>(first);
+#pragma unroll 1
+    for (u32 j = 0; j < nwin; j++) {
+        const u32* row = T + ((size_t)j * E) * n * 16;
+        const Aff base = load_aff_dev(row + (size_t)i * 16);
+        if (!jac_equals_aff<C>(expect, base)) wrong++;
+        Aff prev = base;
+#pragma unroll 1
+        for (u32 e = 2; e <= E; e++) {
+            const Aff cur = load_aff_dev(row + ((size_t)(e - 1) * n + i) * 16);
+            if (!jac_equals_aff<C>(jac_madd<C>(jac_from_aff<C>(prev), base), cur)) wrong++;
+            prev = cur;
+        }
+        expect = jac_dbl<C>(jac_from_aff<C>(prev));       // 2 * E * base = 2^w * base
+    }
+    if (wrong) atomicAdd(bad, (unsigned long long)wrong);
+}
+// fixed-base MSM rows: row[0][i] = P_i, row[r+1][i] = 16 * row[r][i]
+template <class C> __global__ void __launch_bounds__(256)
+k_fb_rows_check(const u32* __restrict__ gens, const u32* __restrict__ T, u32 n, size_t row_points, u32 R, unsigned long long* __restrict__ bad) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 wrong = 0;
+    Jac expect = jac_from_aff<C>(load_aff_dev(gens + (size_t)i * 16));
+#pragma unroll 1
+    for (u32 r = 0; r < R; r++) {
+        const Aff cur = load_aff_dev(T + ((size_t)r * row_points + i) * 16);
+        if (!jac_equals_aff<C>(expect, cur)) wrong++;
+        expect = jac_dbl<C>(jac_dbl<C>(jac_dbl<C>(jac_dbl<C>(jac_from_aff<C>(cur)))));
+    }
+    if (wrong) atomicAdd(bad, (unsigned long long)wrong);
+}
+
 // the first-round uniform fold from the tables: lane t -> V[i] = V[n+i] + t_V * Base(g_first + i*g_stride), V = G (lanes [0, n)) or H.
 // G, H: the working vectors (their upper halves are read, their lower halves written — or the Jacobian workspace, see fold_emit).
 template <class C> __global__ void __launch_bounds__(256)

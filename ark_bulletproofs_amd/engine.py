@@ -752,10 +752,14 @@ class VerifierCS(_ConstraintSystem):
         return lib().bp_verifier_verify(engine.ctx, self.h, bytes(proof), C.c_size_t(len(proof)))
 
 
-def batch_verify_cs(engine, verifiers, proofs, alphas=None, want_point=False):
-    """batch_verify(prng, instances, ..) over VerifierCS objects; alphas: (count, 4) words drawn by the caller (None = ones).
+def batch_verify_cs(engine, verifiers, proofs, alphas, want_point=False):
+    """batch_verify(prng, instances, ..) over VerifierCS objects; alphas: (count, 4) words, the per-instance weights the
+    reference draws from its prng (src/r1cs/verifier.rs:649) — required: equal weights would let the errors of two invalid
+    proofs cancel.  Only a batch of ONE instance (Verifier::verify) may pass None.
     Returns the status, or (status, mega-check point) with want_point."""
     n = len(verifiers)
+    if alphas is None and n > 1:
+        raise ValueError("batch_verify_cs: per-instance weights (alphas) are required for more than one instance")
     hs = (C.c_void_p * max(n, 1))(*[v.h for v in verifiers])
     blob = b"".join(bytes(p) for p in proofs)
     lens = (C.c_size_t * max(n, 1))(*[len(p) for p in proofs])
@@ -820,3 +824,31 @@ def _gens_msm_tables(self, count):
 
 
 Engine.gens_msm_tables = _gens_msm_tables
+
+
+def _gens_tables_check(self):
+    """bp_gens_tables_check: (fold-table entries, fixed-base MSM rows) that break the chain rule — (0, 0) for sound tables"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    check(lib().bp_gens_tables_check(self.ctx, C.byref(a), C.byref(b)), "bp_gens_tables_check")
+    return a.value, b.value
+
+
+def _debug_tables_ptr(self, which):
+    p, n = C.c_void_p(), C.c_size_t(0)
+    check(lib().bp_debug_tables_ptr(self.ctx, int(which), C.byref(p), C.byref(n)), "bp_debug_tables_ptr")
+    return p.value, n.value
+
+
+def _debug_poke(self, dptr, data=None, nbytes=0):
+    """reads (data is None) or writes raw device bytes at an address of this ctx's device (tests corrupt a table entry with it)"""
+    if data is None:
+        out = np.zeros(nbytes, dtype=np.uint8)
+        check(lib().bp_dev_download(self.ctx, ptr(out), C.c_void_p(dptr), C.c_size_t(nbytes)), "bp_dev_download")
+        return out
+    arr = np.ascontiguousarray(data, dtype=np.uint8)
+    check(lib().bp_dev_upload(self.ctx, C.c_void_p(dptr), ptr(arr), C.c_size_t(arr.nbytes)), "bp_dev_upload")
+
+
+Engine.gens_tables_check = _gens_tables_check
+Engine.debug_tables_ptr = _debug_tables_ptr
+Engine.debug_poke = _debug_poke

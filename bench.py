@@ -259,6 +259,8 @@ class ProvePipeline:
 
     def __init__(self, E, engs, args, N):
         self.E, self.engs, self.args, self.N = E, engs, args, N
+        self.keep_info = set()      # statement numbers whose public side (commitments, public values) is kept for a later verify
+        self.infos = {}
 
     def run(self, tag, count, out):
         E, args, engs = self.E, self.args, self.engs
@@ -343,6 +345,8 @@ class ProvePipeline:
                 if i is None:
                     return
                 t1 = time.perf_counter()
+                if i in self.keep_info:
+                    self.infos[i] = built[i].info(m_cap=8)[:2]
                 out[i] = built[i].prove(engs[k])
                 built[i].free()   # a consumed statement (witness + constraints, ~0.3 GB at 2^20) is released at once
                 built[i] = None
@@ -415,11 +419,31 @@ def run_prove(args, rank, world, local):
         pipe.run(100, args.batch * args.warmup, [None] * (args.batch * args.warmup))
     nproofs = args.batch * args.steps
     flat = [None] * nproofs
+    pipe.keep_info = {0, nproofs - 1}
     barrier(world)
     t0 = time.perf_counter()
     pipe.run(0, nproofs, flat)                   # K steps x `batch` proofs, statement construction included
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
+    # The proofs that were timed are checked (after the timed region): the first and the last of the run go through the GPU verifier
+    # — Verifier::verify, src/r1cs/verifier.rs:549-600 — and a copy with one flipped bit of t_x must be rejected; the run fails otherwise.
+    # The precomputed tables the proofs came through are walked entry by entry (bp_gens_tables_check).
+    verified = 0
+    for i in sorted(pipe.keep_info):
+        commits, pubs = pipe.infos[i]
+        proof = flat[i][0]
+        rc = engs[0].verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], proof, commits, pubs)
+        if rc != 0:
+            raise RuntimeError("bench: timed proof %d does not verify (status %d)" % (i, rc))
+        bad = bytearray(proof)
+        bad[11 * 33 + 9] ^= 1
+        rc = engs[0].verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], bytes(bad), commits, pubs)
+        if rc != -4:
+            raise RuntimeError("bench: a tampered copy of timed proof %d was not rejected (status %d)" % (i, rc))
+        verified += 1
+    tables_bad = list(engs[0].gens_tables_check()) if (tab_info or msm_tab_info) else None
+    if tables_bad and any(tables_bad):
+        raise RuntimeError("bench: precomputed table entries fail the chain-rule check: %r" % (tables_bad,))
     # thread-seconds of every stage of the timed pipeline (busy / waiting for its input), as fractions of (threads x wall)
     pipe_util = {k: v / dt for k, v in pipe.waits.items()}
     stages = np.zeros(8)
@@ -446,6 +470,8 @@ def run_prove(args, rank, world, local):
                                % (args.logn, CURVES[args.curve], args.batch, P, args.host_threads, args.build_threads),
                    "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "build_threads": args.build_threads,
                    "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
+                   "verified": verified, "verified_note": "timed proofs 0 and %d verified on the GPU after the timed region, a tampered copy of each rejected" % (nproofs - 1),
+                   "table_entries_failing_check": tables_bad,
                    "pipeline_thread_seconds_per_wall_second": pipe_util, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
@@ -670,8 +696,8 @@ def main():
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
     ap.add_argument("--cpu-verify-proofs", type=int, default=256, help="CPU baseline sample of the verify workload (about 10 s)")
     ap.add_argument("--batch", type=int, default=16, help="independent proofs per step per GPU (prove workload)")
-    ap.add_argument("--host-threads", type=int, default=5, help="host threads running the TranscriptRng head of prove()")
-    ap.add_argument("--build-threads", type=int, default=8, help="host threads constructing statements (Prover::new + commit + gadget)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads running the TranscriptRng head of prove() (0 = 5/16 of this rank's share of the CPU quota)")
+    ap.add_argument("--build-threads", type=int, default=0, help="host threads constructing statements (Prover::new + commit + gadget) (0 = half of this rank's share of the CPU quota)")
     ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--window", type=int, default=64, help="statements alive at once in the prove pipeline (built, waiting for or in the TranscriptRng stage, "
                     "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s")
@@ -687,6 +713,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))        # this process has not touched the GPU
     rank, world, local = dist_setup(args.gpus)
+    # host thread counts of the prove pipeline from this rank's share of the CPUs (the ranks of a node share the cgroup's quota;
+    # measured on a 16-CPU share: 5 + 8 beside the 8 GPU driver threads)
+    share = max(1.0, cpu_quota() / max(world, 1))
+    if args.host_threads <= 0:
+        args.host_threads = max(1, int(round(share * 5 / 16)))
+    if args.build_threads <= 0:
+        args.build_threads = max(2, int(round(share * 8 / 16)))
     res = {"msm": run_msm, "prove": run_prove, "verify": run_verify, "headline": run_headline}[args.workload](args, rank, world, local)
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -160,6 +160,16 @@ int bp_gens_fold_tables(bp_ctx* ctx, size_t count, int window_bits, size_t budge
  * are paid once, the window is wider (c = 20 at 2^21 terms: 13 mixed adds per term instead of 17-18) and the result needs no
  * doublings.  Skewed scalars (0/1 witness vectors) fall back to the ordinary schedule.  Results never depend on it. */
 int bp_gens_msm_tables(bp_ctx* ctx, size_t count, size_t* bytes_out);
+/* Integrity check of both kinds of precomputed tables: every entry is re-derived from its stored neighbours by the chain rule
+ * (e * 2^(w*j) * P = (e-1) * 2^(w*j) * P + 2^(w*j) * P, next window = the doubled last entry; MSM rows: next row = 16 * row) with
+ * mixed additions / doublings compared projectively, anchored at the resident generators; *bad_fold_entries / *bad_msm_rows (either
+ * may be NULL) receive the number of entries that do not fit.  A proof touches only the few rows its challenges select, so a
+ * corrupted entry (a bit flip in 150 GB of HBM, a bad build) cannot be found by proving; this finds it, in about the time of one
+ * proof.  Tables that are not installed count as 0. */
+int bp_gens_tables_check(bp_ctx* ctx, uint64_t* bad_fold_entries, uint64_t* bad_msm_rows);
+/* test hook: device address and size in bytes of a table (which: 0 / 1 fold tables of G / H, layout [window][digit-1][i] x 64 B;
+ * 2 / 3 MSM rows of G / H, layout [row][i] x 64 B); NULL / 0 when not installed */
+int bp_debug_tables_ptr(bp_ctx* ctx, int which, void** dptr, size_t* nbytes);
 /* PedersenGens::default() -> (B, B_blinding); host only */
 int bp_pedersen_gens(int curve, uint64_t B_xy[8], uint64_t B_blinding_xy[8]);
 /* GeneratorsChain for label 'G'|'H' || LE32(party) (src/generators.rs:71-121), first `count` points; host only */
@@ -306,8 +316,12 @@ int bp_verifier_verify(bp_ctx* ctx, bp_cs* verifier, const uint8_t* proof, size_
 /* `batch_verify(prng, instances, &pc_gens, &bp_gens)` (verifier.rs:604-691): instance k = (verifiers[k], the k-th of the
  * concatenated compressed proofs); every verifier is consumed.  Instances whose recordings have the same STRUCTURE (same gadget;
  * coefficient values may differ: public constants, challenge-dependent randomized constraints) are evaluated by one kernel launch
- * per block of 512 from a GPU-resident circuit template.  check_point_xy (may be NULL): the value of the mega-check MSM, all-zero
- * iff it is the identity.  timing (5 doubles, may be NULL) as in bp_r1cs_batch_verify_scenarios. */
+ * per block of 512 from a GPU-resident circuit template.  alphas: count x 4 words (ark Montgomery form), the weights the reference
+ * draws per instance from its prng (verifier.rs:649) — REQUIRED for count > 1 (BP_E_ARG otherwise: with equal weights the errors of
+ * two invalid proofs can cancel in the one mega-check); NULL is accepted for count == 1 only (Verifier::verify, weight 1).  The same
+ * handle twice in one batch is BP_E_ARG at any count.  A verifier created by bp_verifier_new_like that holds fewer commitments than
+ * the shared constraints name is BP_E_ARG (the reference would index past its V vector).  check_point_xy (may be NULL): the value
+ * of the mega-check MSM, all-zero iff it is the identity.  timing (5 doubles, may be NULL) as in bp_r1cs_batch_verify_scenarios. */
 int bp_r1cs_batch_verify(bp_ctx* ctx, size_t count, bp_cs* const* verifiers, const uint8_t* proofs, const size_t* proof_lens, const uint64_t* alphas,
                          double* timing, uint64_t* check_point_xy);
 /* The next instance of the SAME gadget without recording it again: a verifier that shares `of`'s phase-1 constraints and its

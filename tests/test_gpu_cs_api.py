@@ -219,3 +219,44 @@ def test_transcript_state_roundtrip_and_borrowing(E, engines, oracle):
     po.prove(GENS, bytes(32))
     t3 = E.transcript_from_state(after)
     assert t3.challenge_bytes(b"c", 32) == po.transcript().challenge_bytes(b"c", 32)
+
+
+def test_batch_verify_argument_checks(E, engines, oracle):
+    """(a) equal weights are refused for more than one instance (verifier.rs:649 draws one per instance), (b) the same
+    verifier handle twice is refused at ANY batch size, (c) a like-instance that replayed fewer commitments than the shared
+    constraints name is an error, not a silently weaker statement."""
+    curve = 0
+    O, eng = oracle, engines[curve]
+    F = GD.Field(O, curve)
+    kw = dict(n_mul=6, n_extra=0, n_alloc=1)
+    pr, V, _ = product_prove(E, eng, F, 41, 70, 2, False, **kw)
+    lib, C = E.lib(), E.C
+
+    def raw_batch(vs, proofs, alphas):
+        hs = (C.c_void_p * len(vs))(*[v.h for v in vs])
+        lens = (C.c_size_t * len(vs))(*[len(p) for p in proofs])
+        al = None if alphas is None else E.ptr(E.u64arr(alphas, 4))
+        return lib.bp_r1cs_batch_verify(eng.ctx, C.c_size_t(len(vs)), hs, b"".join(proofs), lens, al, None, None)
+
+    # (a) NULL alphas: fine for one instance (Verifier::verify), BP_E_ARG for two; the Python wrapper refuses as well
+    v0 = product_verifier(E, curve, F, 41, V, [], False, **kw)
+    assert raw_batch([v0], [pr], None) == 0
+    va, vb = product_verifier(E, curve, F, 41, V, [], False, **kw), product_verifier(E, curve, F, 41, V, [], False, **kw)
+    assert raw_batch([va, vb], [pr, pr], None) == -1
+    with pytest.raises(ValueError):
+        E.batch_verify_cs(eng, [va, vb], [pr, pr], None)
+    alphas = O.fe_rand(O.fid(curve, True), bytes([3]) * 32, 5000)
+    assert raw_batch([va, vb], [pr, pr], alphas[:2]) == 0           # (the refused calls consumed nothing)
+    # (b) duplicates in a batch above the old 4096 cut-off
+    src = product_verifier(E, curve, F, 41, V, [], False, **kw)
+    many = [src] + [product_verifier(E, curve, F, 41, V, [], False, like=src) for _ in range(4199)]
+    many[4150] = many[7]
+    assert raw_batch(many, [pr] * len(many), alphas[: len(many)]) == -1
+    # (c) a like-instance with one commitment missing
+    src2 = product_verifier(E, curve, F, 41, V, [], False, **kw)
+    t = E.HostTranscript(LABEL)
+    t.append_message(b"dom-sep", b"generic gadget v1")
+    short = E.VerifierCS(curve, t, like=src2)
+    short.commit(V[:1])
+    assert raw_batch([src2, short], [pr, pr], alphas[:2]) == -1
+    assert short.verify(eng, pr) != 0

@@ -241,3 +241,93 @@ def test_zorro_prove_verify_roundtrip_2pow16_and_batch():
         assert rc == -4
     finally:
         e.close()
+
+
+def test_bench_configuration_2pow20_with_tables_checked():
+    """The configuration bench.py times: N = 2^20 on secq256k1 with the first-round fold tables at the
+    automatically chosen window width (w = 8: 146 GB) and the fixed-base MSM rows (8.7 GB).  (a) every entry of both kinds of
+    table passes the chain-rule check, and a single corrupted entry — anywhere, here deep inside the 146 GB — turns it red;
+    (b) prove -> verify -> tamper with the tables in use; (c) the same statement proved with the tables released gives the same
+    proof bytes."""
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+
+    N, cv = 1 << 20, 0
+    e = A.Engine(curve=cv)
+    try:
+        e.gens_derive(N)
+        import torch
+
+        free_b, _ = torch.cuda.mem_get_info(0)
+        budget = int(free_b) - 2 * 65 * 64 * N - 3000 * N - (8 << 30)       # bench.py's rule with one proof in flight
+        wbits, nbytes = e.gens_fold_tables(N // 2, window_bits=0, budget_bytes=max(budget, 1 << 30))
+        assert 2 <= wbits <= 8 and nbytes > 0
+        assert e.gens_msm_tables(N) > 0
+        assert e.gens_tables_check() == (0, 0)
+        # corrupt ONE coordinate word of one entry far inside each table, check, restore, check
+        for which, slot in ((0, 0), (1, 0), (2, 1), (3, 1)):
+            dptr, size = e.debug_tables_ptr(which)
+            assert dptr and size >= 64
+            off = (size // 64 * 5 // 7) * 64 + 24
+            orig = e.debug_poke(dptr + off, nbytes=4)
+            flipped = orig.copy()
+            flipped[1] ^= 0x10
+            e.debug_poke(dptr + off, flipped)
+            bad = e.gens_tables_check()
+            assert bad[slot] >= 1 and bad[1 - slot] == 0, (which, bad)
+            e.debug_poke(dptr + off, orig)
+        assert e.gens_tables_check() == (0, 0)
+        seed = bytes([3, 0, 0, 0, 0]) + bytes([3]) * 27                      # bench.py's statement_seed(0, 0)
+        st = E.Statement(cv, E.SC_SQUARE_CHAIN, [N, 0], seed)
+        commits, pubs, nm, nq = st.info(m_cap=8)
+        proof, _ = st.prove(e)
+        st.free()
+        assert e.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], proof, commits, pubs) == 0
+        bad = bytearray(proof)
+        bad[11 * 33 + 9] ^= 1          # t_x
+        assert e.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], bytes(bad), commits, pubs) == -4
+        # a 2-phase statement of the same size through the same tables (all G factors = u)
+        k = (1 << 19) + 1
+        st2 = E.Statement(cv, E.SC_SHUFFLE, [k], seed, engine=e)
+        commits2, pubs2, _, _ = st2.info(m_cap=2 * k + 8)
+        proof2, _ = st2.prove(e)
+        st2.free()
+        assert e.verify_scenario(E.SC_SHUFFLE, [k], proof2, commits2, pubs2) == 0
+        # tables off: byte-identical proofs
+        e.gens_fold_tables(0)
+        e.gens_msm_tables(0)
+        st = E.Statement(cv, E.SC_SQUARE_CHAIN, [N, 0], seed)
+        proof_off, _ = st.prove(e)
+        st.free()
+        assert proof_off == proof, "the 2^20 proof made with the tables differs from the one made without them"
+        st2 = E.Statement(cv, E.SC_SHUFFLE, [k], seed, engine=e)
+        proof2_off, _ = st2.prove(e)
+        st2.free()
+        assert proof2_off == proof2
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("curve", [0, 1], ids=["secq256k1", "zorro"])
+def test_auto_tables_2pow14_against_oracle_bytes(oracle, curve):
+    """the bench's table settings (automatic window width, fixed-base MSM rows in use) at a size the oracle proves in seconds:
+    proof bytes equal the oracle's for a 1-phase and a 2-phase statement; the tables pass the chain-rule check"""
+    import ark_bulletproofs_amd as A
+
+    N = 1 << 14
+    e = A.Engine(curve=curve)
+    try:
+        e.gens_derive(N)
+        wbits, _ = e.gens_fold_tables(N // 2, window_bits=0)
+        assert wbits == 8
+        e.gens_msm_tables(N)
+        e.set_tuning(5, 4096)          # BP_TUNE_MSM_FIXED_MIN: the fixed-base schedule at these sizes too
+        assert e.gens_tables_check() == (0, 0)
+        for sc, prm, mcap in [(3, [N, 0], 8), (0, [N // 2 + 1], N + 16)]:
+            ref = oracle.r1cs_prove(curve, sc, prm, bytes([7]) * 32, N, m_cap=mcap)
+            assert ref.rc == 0
+            got = e.prove_scenario(sc, prm, bytes([7]) * 32, m_cap=mcap)
+            assert got.proof == ref.proof, (curve, sc)
+            assert e.verify_scenario(sc, prm, got.proof, got.commitments, got.publics) == 0
+    finally:
+        e.close()

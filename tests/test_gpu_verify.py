@@ -316,3 +316,40 @@ def test_verification_gh_scalars_match_reference_formulas(eng, oracle):
     got_g = [O.limbs_to_int(v) for v in g]
     got_h = [O.limbs_to_int(v) for v in h]
     assert got_g == g_exp and got_h == h_exp
+
+
+def test_template_cache_eviction_keeps_what_the_block_uses(oracle):
+    """ADVICE r02 (use-after-free in batch_verify_core): a long-lived ctx that has seen more circuit shapes than its template cache
+    holds, then a block that mixes a NEW shape (first) with shapes whose templates were cached when the replay workers ran.  The
+    eviction must not take a template an instance of the current block resolves to (its recording is already released)."""
+    import ark_bulletproofs_amd as A
+
+    O, cv = oracle, 0
+    e = A.Engine(curve=cv)
+    e.gens_derive(128)
+    try:
+        seed = bytes([11]) * 32
+
+        def stmt(n, tag):
+            pr = e.prove_scenario(3, [n, 0], bytes([tag & 255]) * 32, m_cap=8)   # square chain with n multipliers: one shape per n
+            return (3, [n, 0], pr.proof, pr.commitments, pr.publics)
+
+        shapes = {n: stmt(n, n) for n in range(2, 76)}
+        # fill the cache past its bound: 70 shapes, each twice (a shape used once is recorded inside its own replay)
+        first = [shapes[n] for n in range(2, 72)] * 2
+        rc, _, pt = e.batch_verify(first, seed, want_point=True)
+        assert rc == OK and not pt.any()
+        # new shapes first, then shapes cached by the call above, all in one block; twice each so that every one has a shared source
+        mixed = ([shapes[n] for n in (72, 73, 74, 75)] + [shapes[n] for n in range(40, 72)]) * 2
+        rc, _, pt = e.batch_verify(mixed, seed, want_point=True)
+        assert rc == OK and not pt.any()
+        assert O.batch_verify(cv, mixed[:12], 128, seed) == 0
+        # and a failing instance among them is still found
+        sc, prm, proof, cm, pb = mixed[20]
+        bad = bytearray(proof)
+        bad[11 * 33 + 40] ^= 2
+        mixed[20] = (sc, prm, bytes(bad), cm, pb)
+        rc, _ = e.batch_verify(mixed, seed)
+        assert rc == E_VERIFICATION
+    finally:
+        e.close()
