@@ -1,6 +1,9 @@
 // libarkbp_hip.so — context, workspaces, host orchestration and the C ABI (include/arkbp.h).
 // There is no CPU fallback: without a HIP device every compute entry point returns BP_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the entry points are bound with dlsym (rccl_api)
+#include <dlfcn.h>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -37,6 +40,38 @@ const char* bp_last_error(void) { return g_err.c_str(); }
         }                                                                                           \
     } while (0)
 #define BPCHK(x) do { int r_ = (x); if (r_ != BP_OK) return r_; } while (0)
+
+// ---- native collectives: RCCL over xGMI (BASELINE north_star: "final RCCL point-reduce over xGMI") --------------------------------
+// The library does not link librccl: it binds the five entry points it needs at run time from the RCCL the process already has
+// (a PyTorch-ROCm host brings its own copy) or from the ROCm installation, so a single-GPU host never loads RCCL at all.
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+static RcclApi& rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (h) break; }   // the copy the process already mapped
+        if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+        if (!api.ok) api.why = "librccl lacks an expected entry point";
+    });
+    return api;
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -154,6 +189,13 @@ struct bp_ctx {
     void* shard_user = nullptr;
     bp_allgather_cb gather_cb = nullptr;   // optional: lets the prover partition the IPA index-cyclically (bp_ctx_set_shard_allgather)
     void* gather_user = nullptr;
+    // native collectives (bp_ctx_rccl_init): both exchanges of the sharded mode as ncclAllGather on the ctx's stream
+    ncclComm_t nccl = nullptr;
+    DevBuf coll_send, coll_recv;
+    void* h_coll = nullptr;                // pinned: [send | recv]
+    size_t h_coll_cap = 0;
+    uint64_t coll_count = 0;
+    double coll_seconds = 0;
     size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
     size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
     size_t tune_host_threads = 0;                  // BP_TUNE_HOST_THREADS: size of this ctx's host pool (0 = host_pool_threads())
@@ -189,6 +231,40 @@ static hipError_t ctx_stream_wait(bp_ctx* c) {
     if (e != hipSuccess) return e;
     return hipEventSynchronize(c->sync_ev);
 }
+// all-gather of `bytes` host bytes per rank -> recv (world x bytes, rank order): ncclAllGather on the ctx's stream between a pinned
+// H2D and a pinned D2H copy; the stream order puts it behind the kernels already enqueued
+static int ctx_native_allgather(bp_ctx* c, const void* send, size_t bytes, void* recv) {
+    RcclApi& api = rccl_api();
+    const size_t W = (size_t)c->shard_world;
+    const auto t0 = std::chrono::steady_clock::now();
+    BPCHK(c->coll_send.ensure(bytes)); BPCHK(c->coll_recv.ensure(bytes * W));
+    if (c->h_coll_cap < bytes * (W + 1)) {
+        if (c->h_coll) HIPCHK(hipHostFree(c->h_coll));
+        c->h_coll = nullptr; c->h_coll_cap = 0;
+        HIPCHK(hipHostMalloc(&c->h_coll, bytes * (W + 1) + 4096));
+        c->h_coll_cap = bytes * (W + 1) + 4096;
+    }
+    memcpy(c->h_coll, send, bytes);
+    HIPCHK(hipMemcpyAsync(c->coll_send.p, c->h_coll, bytes, hipMemcpyHostToDevice, c->stream));
+    const ncclResult_t r = api.AllGather(c->coll_send.p, c->coll_recv.p, bytes, ncclUint8, c->nccl, c->stream);
+    if (r != ncclSuccess) { g_err = std::string("ncclAllGather: ") + api.GetErrorString(r); return BP_E_HIP; }
+    HIPCHK(hipMemcpyAsync((char*)c->h_coll + bytes, c->coll_recv.p, bytes * W, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(ctx_stream_wait(c));
+    memcpy(recv, (char*)c->h_coll + bytes, bytes * W);
+    c->coll_count++;
+    c->coll_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return BP_OK;
+}
+// the two exchanges of the sharded mode, through RCCL when the ctx has a communicator, else through the host's callbacks
+static int shard_allgather(bp_ctx* c, const void* send, size_t bytes, void* recv) {
+    if (c->nccl) return ctx_native_allgather(c, send, bytes, recv);
+    if (!c->gather_cb) { g_err = "sharded mode: no all-gather installed"; return BP_E_ARG; }
+    const int rc = c->gather_cb(c->gather_user, send, bytes, recv);
+    if (rc) { g_err = "the all-gather callback failed"; return rc < 0 ? rc : BP_E_ARG; }
+    return BP_OK;
+}
+static inline bool shard_has_allgather(const bp_ctx* c) { return c->nccl || c->gather_cb; }
+
 struct ScopedK {  // records start/stop events around a region when profiling is on
     bp_ctx* c; int which; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
     ScopedK(bp_ctx* c_, int w) : c(c_), which(w), on(c_->profiling) {
@@ -251,6 +327,14 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         if (!sharded) return BP_OK;
         A4 a = G::to_aff(part);
         uint64_t xy[8]; memcpy(xy, a.x.v, 32); memcpy(xy + 4, a.y.v, 32);
+        if (ctx->nccl) {   // RCCL point-reduce: group addition is not an RCCL reduce op -> all-gather of the 64-byte partials + world-1 host additions
+            std::vector<uint64_t> all((size_t)ctx->shard_world * 8);
+            BPCHK(ctx_native_allgather(ctx, xy, 64, all.data()));
+            J4 sum = G::inf();
+            for (int r = 0; r < ctx->shard_world; r++) { A4 q; memcpy(q.x.v, &all[(size_t)r * 8], 32); memcpy(q.y.v, &all[(size_t)r * 8 + 4], 32); sum = G::add(sum, G::from_aff(q)); }
+            part = sum;
+            return BP_OK;
+        }
         const int rc = ctx->shard_cb(ctx->shard_user, xy);
         if (rc) { g_err = "msm: the point-reduce callback failed"; return rc < 0 ? rc : BP_E_ARG; }
         memcpy(a.x.v, xy, 32); memcpy(a.y.v, xy + 4, 32);
@@ -419,14 +503,17 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
                                ctx->bin_cur.as<u32>(), ctx->hist.as<u32>(), ctx->boff.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(), ctx->fs_binch.as<u32>(),
                                d_over, pl, bp, sp, chl_fs);
             {
-                ScopedK acc(ctx, BP_K_MSM_ACCUM);
+                ScopedK acc(ctx, BP_K_MSM_ACCUM_FS);
                 hipLaunchKernelGGL(k_msm_accum_fs<C>, dim3((u32)((maxch + 255) / 256)), dim3(256), 0, st, segs, ctx->slots.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                                    ctx->boff.as<u32>(), ctx->fs_binch.as<u32>(), ctx->lvA.as<u32>(), pl, bp, fp, chl_fs, d_info);
             }
+            {
+            ScopedK agg(ctx, BP_K_MSM_AGG);
             hipLaunchKernelGGL(k_msm_reduce_fs<C>, dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                                ctx->fs_binch.as<u32>(), ctx->fs_sums.as<u32>(), pl, bp, fp, chl_fs, red_g);
             hipLaunchKernelGGL((k_msm_marginals_fs<C, 256>), dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                            ctx->Tbuf.as<u32>(), pl, bp, fp, chl_fs, d_info, d_over);
+            }
             HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tb, hipMemcpyDeviceToHost, st));
             total.stop();
             const double t_f1 = mtrace ? tfs() : 0;
@@ -502,6 +589,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     }
     u32* cur = ctx->lvA.as<u32>();
     u32* nxt = ctx->lvB.as<u32>();
+    ScopedK agg(ctx, BP_K_MSM_AGG);
     for (int k = 2; k <= K; k++) {
         hipLaunchKernelGGL(k_msm_reduce<C>, dim3((tot[k] + TB - 1) / TB), dim3(TB), 0, st, cur, lvl + Bp1 * (k - 1), lvl + Bp1 * k, nxt, pl.B, tot[k], chl,
                            (k == spl + 1 && special) ? b_gen : pl.B);
@@ -511,6 +599,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     }
     if (use_marginals) hipLaunchKernelGGL(k_msm_marginals<C>, dim3(pl.W, pl.c), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl);
     else hipLaunchKernelGGL(k_msm_window_sums<C>, dim3(nblk_ws, pl.W), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl, nblk_ws);
+    agg.stop();
     }
     HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tbytes, hipMemcpyDeviceToHost, st));
     total.stop();
@@ -684,12 +773,15 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     }
     u32* cur = ctx->lvA.as<u32>();
     u32* nxt = ctx->lvB.as<u32>();
+    {
+    ScopedK agg(ctx, BP_K_MSM_AGG);
     for (int k = 2; k <= K; k++) {
         hipLaunchKernelGGL(k_msm_reduce<C>, dim3((tot[k] + 255) / 256), dim3(256), 0, st, cur, lvl + Bp1 * (k - 1), lvl + Bp1 * k, nxt, pl.B, tot[k], chl, pl.B);
         u32* t2 = cur; cur = nxt; nxt = t2;
     }
     hipLaunchKernelGGL(k_msm_window_sums<C>, dim3(nblk_ws, 1), dim3(256), 0, st, cur, lvl + Bp1 * K, ctx->Tbuf.as<u32>(), pl1, nblk_ws);
     hipLaunchKernelGGL(k_msm_sum_partials<C>, dim3(1), dim3(256), 0, st, ctx->Tbuf.as<u32>(), nblk_ws, ctx->Tbuf.as<u32>() + (size_t)nblk_ws * 24);
+    }
     HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.as<u32>() + (size_t)nblk_ws * 24, 96, hipMemcpyDeviceToHost, st));
     total.stop();
     HIPCHK(ctx_stream_wait(ctx));
@@ -872,10 +964,11 @@ static int fold_finish_plan(bp_ctx* ctx, size_t lanes, FoldFinish& ff) {
     ff.m = (u32)std::min<size_t>(8, std::max<size_t>(2, lanes / 32768));   // keep >= 2^15 lanes busy
     return BP_OK;
 }
-template <class C> static void fold_finish_launch(hipStream_t st, const FoldFinish& ff, u32* d_G, u32* d_H, size_t n, int which, size_t lanes) {
+template <class C> static void fold_finish_launch(bp_ctx* ctx, const FoldFinish& ff, u32* d_G, u32* d_H, size_t n, int which, size_t lanes) {
     if (!ff.jac) return;
+    ScopedK tk(ctx, BP_K_FOLD_FINISH);
     const u32 threads = (u32)((lanes + ff.m - 1) / ff.m);
-    hipLaunchKernelGGL(k_ipa_fold_finish<C>, dim3((threads + 255) / 256), dim3(256), 0, st, ff.jac, ff.pref, d_G, d_H, (u32)n, which, (u32)lanes, ff.m);
+    hipLaunchKernelGGL(k_ipa_fold_finish<C>, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, ff.jac, ff.pref, d_G, d_H, (u32)n, which, (u32)lanes, ff.m);
 }
 // launches the uniform fold for multipliers (tG, tH): GLV ladder where the curve has the endomorphism, plain NAF ladder otherwise
 template <class C> static int launch_uniform_fold(bp_ctx* ctx, u32* d_G, u32* d_H, size_t n, const F4& tG, const F4& tH, int which) {
@@ -885,6 +978,8 @@ template <class C> static int launch_uniform_fold(bp_ctx* ctx, u32* d_G, u32* d_
     FoldFinish ff;
     BPCHK(fold_finish_plan(ctx, lanes, ff));
     bool done = false;
+    {
+    ScopedK tk(ctx, BP_K_FOLD_LADDER);
     if constexpr (C::HAS_GLV) {
         Naf2 g, h;
         if (glv_pair<C>(tG, tH, g, h)) {
@@ -896,7 +991,8 @@ template <class C> static int launch_uniform_fold(bp_ctx* ctx, u32* d_G, u32* d_
         Naf a = naf_of<S>(tG), b = naf_of<S>(tH);
         hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, a, b, which, ff.jac);
     }
-    fold_finish_launch<C>(st, ff, d_G, d_H, n, which, lanes);
+    }
+    fold_finish_launch<C>(ctx, ff, d_G, d_H, n, which, lanes);
     return BP_OK;
 }
 
@@ -1005,9 +1101,12 @@ template <class C> static int launch_tab_fold(bp_ctx* ctx, const IpaState& s, u3
     const u32 lanes = (u32)(2 * n);
     FoldFinish ff;
     BPCHK(fold_finish_plan(ctx, lanes, ff));
+    {
+    ScopedK tk(ctx, BP_K_FOLD_TAB);
     hipLaunchKernelGGL(k_ipa_fold_tab<C>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, ctx->ftab_G.as<u32>(), ctx->ftab_H.as<u32>(), (u32)ctx->ftab_n,
                        1u << (ctx->ftab_w - 1), d_G, d_H, (u32)n, dG, dH, 3, s.gens_first, s.gens_stride, ff.jac, s.d_G_in, s.d_H_in);
-    fold_finish_launch<C>(ctx->stream, ff, d_G, d_H, n, 3, lanes);
+    }
+    fold_finish_launch<C>(ctx, ff, d_G, d_H, n, 3, lanes);
     done = true;
     return BP_OK;
 }
@@ -1164,7 +1263,7 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
             FoldFinish ff;
             BPCHK(fold_finish_plan(ctx, n, ff));
             hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3(gb), dim3(256), 0, st, d_G, d_H, s.d_Gf, s.d_Hf, 1, (u32)n, words_of<S>(u), words_of<S>(ui), 2, ff.jac);
-            fold_finish_launch<C>(st, ff, d_G, d_H, n, 2, n);
+            fold_finish_launch<C>(ctx, ff, d_G, d_H, n, 2, n);
             s.gamma_G = S::mul(s.gamma_G, s2);
             s.pending = true;
         } else if (first) {
@@ -1173,7 +1272,7 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
             BPCHK(fold_finish_plan(ctx, 2 * n, ff));
             hipLaunchKernelGGL(k_ipa_fold_pts<C>, dim3((u32)((2 * n + 255) / 256)), dim3(256), 0, st, d_G, d_H, s.d_Gf, s.d_Hf, 1, (u32)n, words_of<S>(u),
                                words_of<S>(ui), 3, ff.jac);
-            fold_finish_launch<C>(st, ff, d_G, d_H, n, 3, 2 * n);
+            fold_finish_launch<C>(ctx, ff, d_G, d_H, n, 3, 2 * n);
         } else {
             // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
             // (geometric pending factor: c[i]/c[n+i] = rho^-n joins t, and K picks up rho^n)
@@ -1320,7 +1419,7 @@ static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const
         HIPCHK(hipMemcpyAsync(send.data(), o, per, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx_stream_wait(ctx));
     }
-    { const int rc = ctx->gather_cb(ctx->gather_user, send.data(), per, recv.data()); if (rc) { g_err = "ipa: the all-gather callback failed"; return rc < 0 ? rc : BP_E_ARG; } }
+    BPCHK(shard_allgather(ctx, send.data(), per, recv.data()));
     std::vector<F4> ga(S_glob), gbv(S_glob);
     std::vector<A4> gG(S_glob), gH(S_glob);
     for (size_t rr = 0; rr < W; rr++) {
@@ -1366,7 +1465,7 @@ static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const
 // whether a sharded prover can partition an IPA of padded size N this way
 static inline bool ipa_cyclic_applies(const bp_ctx* ctx, size_t N) {
     const size_t W = (size_t)ctx->shard_world;
-    if (W <= 1 || !ctx->gather_cb || (W & (W - 1)) || N < ctx->tune_cyclic_min) return false;
+    if (W <= 1 || !shard_has_allgather(ctx) || (W & (W - 1)) || N < ctx->tune_cyclic_min) return false;
     size_t S_glob = std::max<size_t>(std::max<size_t>(ctx->tune_ipa_freeze_len, W), 2);
     { size_t p = 1; while (p < S_glob) p <<= 1; S_glob = p; }
     return N >= 2 * S_glob && N / W >= 2;   // at least one partitioned round
@@ -1860,6 +1959,9 @@ void bp_ctx_destroy(bp_ctx* c) {
     if (c->h_csc) (void)hipHostFree(c->h_csc);
     if (c->h_dec) (void)hipHostFree(c->h_dec);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->nccl) { (void)rccl_api().CommDestroy(c->nccl); c->nccl = nullptr; }
+    c->coll_send.release(); c->coll_recv.release();
+    if (c->h_coll) (void)hipHostFree(c->h_coll);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1867,6 +1969,51 @@ int bp_ctx_set_window_shard(bp_ctx* c, int rank, int world, bp_point_reduce_cb c
     if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !cb)) return BP_E_ARG;
     c->shard_rank = rank; c->shard_world = world; c->shard_cb = cb; c->shard_user = user;
     return BP_OK;
+}
+int bp_rccl_unique_id(uint8_t out[128]) {
+    if (!out) return BP_E_ARG;
+    RcclApi& api = rccl_api();
+    if (!api.ok) { g_err = "RCCL unavailable: " + api.why; return BP_E_HIP; }
+    ncclUniqueId id;
+    const ncclResult_t r = api.GetUniqueId(&id);
+    if (r != ncclSuccess) { g_err = std::string("ncclGetUniqueId: ") + api.GetErrorString(r); return BP_E_HIP; }
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out, &id, 128);
+    return BP_OK;
+}
+int bp_ctx_rccl_init(bp_ctx* c, const uint8_t unique_id[128], int rank, int world) {
+    if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return BP_E_ARG;
+    RcclApi& api = rccl_api();
+    if (!api.ok) { g_err = "RCCL unavailable: " + api.why; return BP_E_HIP; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->nccl) { (void)api.CommDestroy(c->nccl); c->nccl = nullptr; }
+    ncclUniqueId id; memcpy(&id, unique_id, 128);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = api.CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) { g_err = std::string("ncclCommInitRank: ") + api.GetErrorString(r); return BP_E_HIP; }
+    c->nccl = comm;
+    c->shard_rank = rank; c->shard_world = world;
+    c->shard_cb = nullptr; c->shard_user = nullptr; c->gather_cb = nullptr; c->gather_user = nullptr;
+    c->coll_count = 0; c->coll_seconds = 0;
+    return BP_OK;
+}
+int bp_ctx_rccl_shutdown(bp_ctx* c) {
+    if (!c) return BP_E_ARG;
+    if (c->nccl) { HIPCHK(hipSetDevice(c->device)); HIPCHK(ctx_stream_wait(c)); (void)rccl_api().CommDestroy(c->nccl); c->nccl = nullptr; }
+    c->shard_rank = 0; c->shard_world = 1;
+    return BP_OK;
+}
+int bp_ctx_collective_stats(bp_ctx* c, uint64_t* count, double* seconds) {
+    if (!c) return BP_E_ARG;
+    if (count) *count = c->coll_count;
+    if (seconds) *seconds = c->coll_seconds;
+    return BP_OK;
+}
+int bp_debug_rccl_allgather(bp_ctx* c, const uint8_t* send, size_t bytes, uint8_t* recv) {
+    if (!c || !send || !recv || !bytes) return BP_E_ARG;
+    if (!c->nccl) { g_err = "no RCCL communicator on this ctx (bp_ctx_rccl_init)"; return BP_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return ctx_native_allgather(c, send, bytes, recv);
 }
 int bp_ctx_set_shard_allgather(bp_ctx* c, bp_allgather_cb cb, void* user) {
     if (!c) return BP_E_ARG;

@@ -852,3 +852,39 @@ def _debug_poke(self, dptr, data=None, nbytes=0):
 Engine.gens_tables_check = _gens_tables_check
 Engine.debug_tables_ptr = _debug_tables_ptr
 Engine.debug_poke = _debug_poke
+
+
+# ---- native collectives (RCCL inside the library) -------------------------------------------------------------------------
+def rccl_unique_id():
+    """ncclGetUniqueId (128 bytes): one rank makes it, the host's bootstrap hands it to the others"""
+    out = C.create_string_buffer(128)
+    check(lib().bp_rccl_unique_id(out), "bp_rccl_unique_id")
+    return out.raw
+
+
+def _rccl_init(self, unique_id, rank, world):
+    """ncclCommInitRank on this ctx (collective): window-sharded mode with both exchanges as ncclAllGather on the ctx's stream"""
+    check(lib().bp_ctx_rccl_init(self.ctx, bytes(unique_id), int(rank), int(world)), "bp_ctx_rccl_init")
+
+
+def _rccl_shutdown(self):
+    check(lib().bp_ctx_rccl_shutdown(self.ctx), "bp_ctx_rccl_shutdown")
+
+
+def _collective_stats(self):
+    n, s = C.c_uint64(0), C.c_double(0)
+    check(lib().bp_ctx_collective_stats(self.ctx, C.byref(n), C.byref(s)), "bp_ctx_collective_stats")
+    return n.value, s.value
+
+
+def _debug_rccl_allgather(self, block, world):
+    blk = np.ascontiguousarray(block, dtype=np.uint8).reshape(-1)
+    out = np.zeros((world, blk.size), dtype=np.uint8)
+    check(lib().bp_debug_rccl_allgather(self.ctx, ptr(blk), C.c_size_t(blk.size), ptr(out)), "bp_debug_rccl_allgather")
+    return out
+
+
+Engine.rccl_init = _rccl_init
+Engine.rccl_shutdown = _rccl_shutdown
+Engine.collective_stats = _collective_stats
+Engine.debug_rccl_allgather = _debug_rccl_allgather

@@ -7,7 +7,9 @@ local (world-1)-add point-reduce).  SURVEY.md §8(e).
   window_sharded_msm    window sharding: every rank holds all terms and owns a range of Pippenger windows
   sharded_batch_verify  whole proofs per rank; by linearity the sum of the per-rank mega-check points is the
                         reference's single MSM (src/r1cs/verifier.rs:685)
-  enable_window_sharding  whole prover / verifier calls with every inner MSM window-sharded (bp_ctx_set_window_shard)
+  enable_window_sharding  whole prover / verifier calls with every inner MSM window-sharded (bp_ctx_set_window_shard);
+                          the exchanges go through host callbacks (any torch.distributed backend: gloo in the CPU tests)
+  enable_native_sharding  the same partition with the exchanges as ncclAllGather inside the library (bp_ctx_rccl_init)
   sharded_ipa_create    InnerProductProof::create with every vector partitioned index-cyclically (rank r owns the elements
                         i = r mod world): element i and its fold partner n/2 + i live on the same rank, so all folds are
                         local; a round exchanges one pair of partial (L, R) points per rank
@@ -141,6 +143,27 @@ def enable_window_sharding(engine, curve, points_sum, rank, world, group=None, d
 
     engine.set_window_shard(rank, world, reduce_fn if world > 1 else None)
     engine.set_shard_allgather(gather_bytes if (world > 1 and cyclic_ipa) else None)
+
+
+def enable_native_sharding(engine, rank, world, group=None, device=None):
+    """The same partition with the collectives INSIDE the library (bp_ctx_rccl_init): rank 0 draws an ncclUniqueId, this host
+    layer only carries its 128 bytes to the other ranks (one torch.distributed broadcast), and from then on every exchange of
+    the sharded prover / verifier — the per-MSM point-reduce and the one vector gather of the index-cyclic inner-product
+    argument — is an ncclAllGather on the engine's own HIP stream.  No Python, no interpreter lock on the data path."""
+    import torch
+    import torch.distributed as dist
+
+    from . import engine as E
+
+    if world <= 1:
+        engine.rccl_shutdown()
+        return
+    buf = np.frombuffer(E.rccl_unique_id(), dtype=np.uint8).copy() if rank == 0 else np.zeros(128, dtype=np.uint8)
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=0, group=group)
+    engine.rccl_init(t.cpu().numpy().tobytes(), rank, world)
 
 
 def sharded_batch_verify(curve, instances, local_batch_verify, points_sum, rank, world, group=None, device=None):

@@ -37,6 +37,40 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DTYPE = "u32x9 (256-bit modular integers, radix 2^29)"
+# Integer-VALU ceiling for one Montgomery product of the kernels' field arithmetic (csrc/fp29.cuh), from the guide's issue rates
+# (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz max clock, a wave64 VALU instruction occupies its SIMD for 2 cycles; the
+# guide has no row for v_mad_u64_u32 — tools/ubench.hip measures 0.95 wave-instructions per clock and CU, i.e. one per 4 cycles
+# and SIMD: quarter rate) and the instruction mix of one product in the shipped code object (162 v_mad_u64_u32 + ~100 full-rate
+# carry / mask / move instructions, counted in the ISA):  cycles per wave-product and SIMD = 162 * 4 + 100 * 2 = 848.
+VALU_MAD64_PER_PRODUCT, VALU_OTHER_PER_PRODUCT = 162, 100
+VALU_CYCLES_PER_PRODUCT = VALU_MAD64_PER_PRODUCT * 4 + VALU_OTHER_PER_PRODUCT * 2
+VALU_PEAK_GMODMUL = 256 * 4 * 2.4e9 / VALU_CYCLES_PER_PRODUCT * 64 / 1e9        # 185.5 G modmul/s at the maximum clock
+VALU_MEASURED_GMODMUL = 169.0      # tools/ubench.hip on this GPU (profiles/r01_ubench_radix29.txt): the clock the chip holds under this load
+VALU_INSTR_PER_PRODUCT = VALU_MAD64_PER_PRODUCT + VALU_OTHER_PER_PRODUCT
+MADD_PRODUCTS, JADD_PRODUCTS, DBL_PRODUCTS = 11, 16, 7        # modular products of a mixed addition / Jacobian addition / doubling (csrc/ec.cuh)
+
+
+def valu_entry(products, seconds, note):
+    """the integer-VALU view of a kernel (group): modular products it needs / its time, against the guide-derived ceiling"""
+    rate = products / seconds / 1e9
+    return {"unit": "G modmul/s", "achieved": rate, "peak": VALU_PEAK_GMODMUL, "frac": rate / VALU_PEAK_GMODMUL,
+            "measured_rate": VALU_MEASURED_GMODMUL, "frac_of_measured_rate": rate / VALU_MEASURED_GMODMUL,
+            "products": products, "valu_instructions": products * VALU_INSTR_PER_PRODUCT,
+            "peak_derivation": "256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / (162 v_mad_u64_u32 x 4 cyc + 100 full-rate x 2 cyc)", "note": note}
+
+
+def kernel_entry(name, ms, launches, alg_bytes, traffic, products, note=""):
+    """one row of roofline.kernels: everything per UNIT (one proof / one launch, stated in `per`)"""
+    sec = ms * 1e-3
+    e = {"kernel": name, "ms": ms, "launches": launches, "algorithmic_bytes": alg_bytes, "hbm_GBps": alg_bytes / sec / 1e9 if sec > 0 else None,
+         "hbm_frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None, "counter_traffic_bytes": traffic,
+         "traffic_ratio": (traffic / alg_bytes) if (traffic and alg_bytes) else None, "products": products,
+         "valu_instructions": products * VALU_INSTR_PER_PRODUCT if products else None,
+         "valu_G_modmul_per_s": products / sec / 1e9 if (products and sec > 0) else None,
+         "valu_frac": products / sec / 1e9 / VALU_PEAK_GMODMUL if (products and sec > 0) else None}
+    if note:
+        e["note"] = note
+    return e
 CURVES = ["secq256k1", "zorro"]
 
 COLL_DEVICE = "cuda"   # where the collectives' tensors live ("cuda" over RCCL; None = CPU tensors over gloo, rehearsal only)
@@ -178,7 +212,8 @@ def pmc_traffic(keys, applicable, fname, field="largest"):
     if not applicable:
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        f3 = os.path.join(ROOT, "profiles", fname.replace("r02_", "r03_"))
+        d = json.load(open(f3 if os.path.exists(f3) else os.path.join(ROOT, "profiles", fname)))
         tot = 0.0
         for k in ([keys] if isinstance(keys, str) else keys):
             tot += (2.0 * d[k]["fetch_KiB_" + field] + d[k]["write_KiB_" + field]) * 1024.0
@@ -216,6 +251,8 @@ def run_msm(args, rank, world, local):
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     acc_ms, acc_n = eng.kernel_time(0)
+    fs_ms, fs_n = eng.kernel_time(9)            # the fixed-shape pipeline's accumulate has its own timer
+    acc_ms, acc_n = acc_ms + fs_ms, acc_n + fs_n
     tot_ms, tot_n = eng.kernel_time(1)
     res = {
         "metric": "msm_terms_per_sec", "value": n * (1 if args.shard == "windows" else world) * args.steps / dt, "unit": "terms/s", "n_gpus": world, "steps": args.steps,
@@ -234,9 +271,14 @@ def run_msm(args, rank, world, local):
         W, c = E.msm_window_count(args.curve, n)
         full_windows = [256, 255][args.curve] // c          # the remaining top window holds at most a few bits
         madds = n * full_windows * (1.0 - 0.5 ** c)          # non-zero signed digits of uniform scalars
-        res["roofline"]["valu"] = {"unit": "G mixed adds/s", "achieved": madds / avg_s / 1e9, "peak": 12.9, "frac": madds / avg_s / 1e9 / 12.9,
-                                   "note": "the kernel is integer-VALU-bound: gathered mixed Jacobian+affine additions (11 modular products each) against "
-                                           "the measured add rate of this GPU (tools/ubench.hip, profiles/r01_ubench_radix29.txt)"}
+        res["roofline"]["valu"] = valu_entry(madds * MADD_PRODUCTS, avg_s, "the kernel is integer-VALU-bound: gathered mixed Jacobian+affine additions (11 modular products "
+                                             "each; tools/ubench.hip measures 12.9 G mixed adds/s = 142 G modmul/s for the addition as a whole)")
+        agg_ms, agg_n = eng.kernel_time(10)
+        res["roofline"]["kernels"] = [kernel_entry("k_msm_accum_fs | k_msm_accum", acc_ms / acc_n, 1, n * 96.0, res["roofline"]["traffic"], madds * MADD_PRODUCTS),
+                                      kernel_entry("bucket reduction + aggregation (k_msm_reduce_fs, k_msm_marginals_fs)", agg_ms / max(agg_n, 1), 2, None, None, None,
+                                                   "latency-bound trees: ~%d buckets" % (W * (1 << (c - 1))))]
+        res["roofline"]["wall_ms_per_msm"] = dt / args.steps * 1e3
+        res["roofline"]["kernels_over_wall"] = (tot_ms / max(tot_n, 1)) / (dt / args.steps * 1e3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         res["cpu_baseline"] = cpu_baseline_msm(args, bases, sc)
     db.free()
@@ -261,12 +303,15 @@ class ProvePipeline:
         self.E, self.engs, self.args, self.N = E, engs, args, N
         self.keep_info = set()      # statement numbers whose public side (commitments, public values) is kept for a later verify
         self.infos = {}
+        self.ordered = False        # prove the statements strictly in index order (window-sharded ranks must issue their collectives in the same order)
 
     def run(self, tag, count, out):
         E, args, engs = self.E, self.args, self.engs
-        window = max(16, args.window)
+        window = max(8, args.window)
         built = [None] * count
         built_ev = [threading.Event() for _ in range(count)]
+        pre_ev = [threading.Event() for _ in range(count)]
+        nxt_ordered = [0]
         slots = threading.Semaphore(window)
         stop = threading.Event()
         lock = threading.Lock()
@@ -327,7 +372,9 @@ class ProvePipeline:
                 t1 = time.perf_counter()
                 E.precompute_batch([built[g] for g in grp])   # 8 chains in lockstep in AVX-512 lanes (Keccak-f x8)
                 for g in grp:
-                    ready.put(g)
+                    pre_ev[g].set()
+                    if not self.ordered:
+                        ready.put(g)
                 acct("rng_wait_build", t1 - t0)
                 acct("rng_busy", time.perf_counter() - t1)
 
@@ -335,15 +382,22 @@ class ProvePipeline:
         def stage2(k):
             while True:
                 t0 = time.perf_counter()
-                try:
-                    i = ready.get(timeout=0.2)
-                except queue.Empty:
-                    acct("gpu_wait_ready", time.perf_counter() - t0)
-                    if stop.is_set():
+                if self.ordered:
+                    with lock:
+                        i = nxt_ordered[0]
+                        nxt_ordered[0] += 1
+                    if i >= count or not wait(pre_ev[i]):
                         return
-                    continue
-                if i is None:
-                    return
+                else:
+                    try:
+                        i = ready.get(timeout=0.2)
+                    except queue.Empty:
+                        acct("gpu_wait_ready", time.perf_counter() - t0)
+                        if stop.is_set():
+                            return
+                        continue
+                    if i is None:
+                        return
                 t1 = time.perf_counter()
                 if i in self.keep_info:
                     self.infos[i] = built[i].info(m_cap=8)[:2]
@@ -413,8 +467,25 @@ def run_prove(args, rank, world, local):
         # the ranks must issue their per-MSM collectives in the same order)
         from ark_bulletproofs_amd import parallel as PP
 
-        PP.enable_window_sharding(engs[0], args.curve, E.host_points_sum, rank, world, device=COLL_DEVICE)
+        if COLL_DEVICE is not None and not os.environ.get("ARKBP_BENCH_PY_COLLECTIVES"):
+            # the collectives inside the library: ncclAllGather on the ctx's stream (bp_ctx_rccl_init); this layer only carries the unique id
+            PP.enable_native_sharding(engs[0], rank, world, device=COLL_DEVICE)
+            native = True
+        else:
+            # rehearsal on one GPU (gloo) or A/B: the exchanges go through host callbacks into torch.distributed
+            coll_stat = {"n": 0, "s": 0.0}
+
+            def counted_allgather(arr, _ag=PP.allgather_words):
+                t_c = time.perf_counter()
+                out_c = _ag(arr, None, COLL_DEVICE)
+                coll_stat["n"] += 1
+                coll_stat["s"] += time.perf_counter() - t_c
+                return out_c
+
+            PP.enable_window_sharding(engs[0], args.curve, E.host_points_sum, rank, world, device=COLL_DEVICE, allgather=counted_allgather)
+            native = False
     pipe = ProvePipeline(E, engs, args, N)
+    pipe.ordered = window_sharded
     if args.warmup:
         pipe.run(100, args.batch * args.warmup, [None] * (args.batch * args.warmup))
     nproofs = args.batch * args.steps
@@ -444,6 +515,13 @@ def run_prove(args, rank, world, local):
     tables_bad = list(engs[0].gens_tables_check()) if (tab_info or msm_tab_info) else None
     if tables_bad and any(tables_bad):
         raise RuntimeError("bench: precomputed table entries fail the chain-rule check: %r" % (tables_bad,))
+    coll_info = None
+    if window_sharded:
+        cn, cs = engs[0].collective_stats() if native else (coll_stat["n"], coll_stat["s"])
+        coll_info = {"native_rccl_in_library": native, "count": int(cn), "per_proof": cn / max(1, nproofs + args.batch * args.warmup + 2 * len(pipe.keep_info)),
+                     "avg_latency_us": cs / max(cn, 1) * 1e6, "total_s": cs,
+                     "note": "all-gathers of one 64-byte partial point per MSM (+ one vector gather per proof for the index-cyclic IPA), counted since the ctx entered the sharded "
+                             "mode (warm-up and the post-run verification included in `count`)"}
     # thread-seconds of every stage of the timed pipeline (busy / waiting for its input), as fractions of (threads x wall)
     pipe_util = {k: v / dt for k, v in pipe.waits.items()}
     stages = np.zeros(8)
@@ -471,43 +549,96 @@ def run_prove(args, rank, world, local):
                    "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "build_threads": args.build_threads,
                    "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
                    "verified": verified, "verified_note": "timed proofs 0 and %d verified on the GPU after the timed region, a tampered copy of each rejected" % (nproofs - 1),
-                   "table_entries_failing_check": tables_bad,
+                   "table_entries_failing_check": tables_bad, "collectives": coll_info,
                    "pipeline_thread_seconds_per_wall_second": pipe_util, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
     if fold_n:
-        # dominant kernel group: the IPA G/H fold (k_ipa_fold_glv | k_ipa_fold_uniform, k_ipa_fold_finish, k_ipa_fold_ab).  Per proof it
-        # reads 4*64 B and writes 2*64 B per folded pair of points plus 4*32 + 2*32 B of scalars, over sum_j n_j = N-1 pairs
-        # => 576 B * (N-1)  (SURVEY.md §8d); the unit of `achieved`, `traffic` and the time is "all fold launches of one proof".
+        # Dominant kernel group: the IPA G/H fold (k_ipa_fold_tab [round 1], k_ipa_fold_glv | k_ipa_fold_uniform, k_ipa_fold_finish,
+        # k_ipa_fold_ab).  Per proof it reads 4*64 B and writes 2*64 B per folded pair of points plus 4*32 + 2*32 B of scalars, over
+        # sum_j n_j = N-1 pairs => 576 B * (N-1); the unit of `achieved`, `traffic` and the time is "all fold
+        # launches of ONE proof".  Times: one proof run alone after the timed region, HIP events on the ctx's stream.
         per_proof_s = fold_ms * 1e-3
-        # secondary, the bound that actually applies (integer VALU): modular products of the fold ladders against the measured
-        # product rate of this GPU (tools/ubench.hip, profiles/r01_ubench_radix29.txt: 169 G modmul/s).  Per output point:
-        # secq256k1 (GLV): 130 doublings x 7 + ~88 mixed adds x 11 + ~70 (endomorphism, shared inversion, conversions);
-        # zorro: 257 x 8 + ~87 x 11 + ~70.
+        # modular products per output point of a ladder round — secq256k1 (GLV): 130 doublings x 7 + ~88 mixed adds x 11 + ~70
+        # (endomorphism, shared inversion, conversions); zorro: 257 x 8 + ~87 x 11 + ~70
         per_lane = 1950.0 if args.curve == 0 else 3080.0
-        if tab_info:
+        tab_ms, tab_n = engs[0].kernel_time(6)
+        lad_ms, lad_n = engs[0].kernel_time(7)
+        fin_ms, fin_n = engs[0].kernel_time(8)
+        accfs_ms, accfs_n = engs[0].kernel_time(9)
+        agg_ms, agg_n = engs[0].kernel_time(10)
+        acc_n = engs[0].kernel_time(0)[1]
+        if tab_info and tab_n:
             # round 1 (N of the 2(N-1) output points) goes through the fold tables: per point nwin look-ups per scalar half, each a
-            # mixed add (11) — with the GLV halves 2 * nwin adds + nwin endomorphism products —, the final add and the shared inversion
+            # mixed add (11) — with the GLV halves 2 * nwin adds + nwin endomorphism products —, the final add; conversions
             wb = tab_info["window_bits"]
             nwin = (130 if args.curve == 0 else 256) // wb + 1
-            per_lane_tab = (2 * nwin * 11 + nwin if args.curve == 0 else nwin * 11) + 11 + 20
-            modmul = N * per_lane_tab + (N - 2.0) * per_lane
+            per_lane_tab = (2 * nwin * 11 + nwin if args.curve == 0 else nwin * 11) + 11
+            prod_tab, prod_lad = N * per_lane_tab, (N - 2.0) * (per_lane - 20)
         else:
-            modmul = 2.0 * (N - 1) * per_lane
+            prod_tab, prod_lad = 0.0, 2.0 * (N - 1) * (per_lane - 20)
+        prod_fin = 2.0 * (N - 1) * 20           # shared inversion (450 / 8 per point) + 3 products to (X/Z^2, Y/Z^3) + canonical forms
+        modmul = prod_tab + prod_lad + prod_fin
+        secq20 = args.logn == 20 and args.curve == 0 and bool(args.fold_tables)
+        pf = "r02_pmc_prove2p20_summary.json"
+
+        def tr(keys, field="all_launches"):
+            return pmc_traffic(keys, secq20, pf, field)
+
+        # MSM terms of one proof: commitments (2n+1) + (n+1) + (2n+1), then L and R of every round: 2 * (2 n_j + 1)
+        msm_terms = (5 * N + 3) + sum(2 * (2 * (N >> (j + 1)) + 1) for j in range(args.logn))
+        cW = E.msm_window_count(args.curve, max(N, 64))
+        madds_per_term = (255 if args.curve else 256) // cW[1]       # ordinary schedule; the fixed-base schedule needs fewer (c = 20)
+        kernels = [
+            kernel_entry("k_ipa_fold_tab (round 1: fixed-base table look-ups)", tab_ms, tab_n, 576.0 * (N // 2), tr("prove2p20/k_ipa_fold_tab<Secq>"), prod_tab,
+                         "traffic includes the table rows it streams (34 rows x 64 B per point at w = 8): deliberate, 0.3 ms at HBM speed for ~12 ms of ladder saved"),
+            kernel_entry("k_ipa_fold_glv | k_ipa_fold_uniform (rounds >= 2: scalar-multiplication ladders)", lad_ms, lad_n, 576.0 * (N // 2 - 1),
+                         tr("prove2p20/k_ipa_fold_glv<Secq>"), prod_lad, "a round below 2^16 lanes takes ~1.15 ms whatever its size: one lane's serial ladder"),
+            kernel_entry("k_ipa_fold_finish (Jacobian -> affine, one inversion per 8 points)", fin_ms, fin_n, 2.0 * (N - 1) * (96 + 64), tr("prove2p20/k_ipa_fold_finish<Secq>"), prod_fin,
+                         "re-reads the Jacobian results the ladders wrote (unfused: 0.58 GB per proof, 0.07 ms at HBM speed)"),
+            kernel_entry("k_msm_accum (MSMs above 2^18 buckets and the fixed-base MSMs)", acc_ms, acc_n, None, tr("prove2p20/k_msm_accum<Secq>"), None),
+            kernel_entry("k_msm_accum_fs (fixed-shape pipeline: the mid-size L / R MSMs)", accfs_ms, accfs_n, None, tr("prove2p20/k_msm_accum_fs<Secq>"), None),
+            kernel_entry("MSM bucket reduction + aggregation (k_msm_reduce*, k_msm_marginals*, k_msm_window_sums)", agg_ms, agg_n, None, None, None, "latency-bound trees"),
+        ]
+        # the two accumulate rows share the proof's MSM terms: algorithmic bytes and products for their sum
+        acc_all_ms = acc_ms + accfs_ms
         res["roofline"] = {"bound": "hbm", "kernel": "IPA G/H fold (k_ipa_fold_tab [round 1] + k_ipa_fold_glv + k_ipa_fold_finish + k_ipa_fold_ab), all rounds of one proof",
+                           "per": "one 2^%d proof (all launches of the kernel group), run alone after the timed region" % args.logn,
                            "achieved": 576.0 * (N - 1) / per_proof_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 576.0 * (N - 1) / per_proof_s / 1e9 / HBM_PEAK_GBS,
                            # HBM bytes of all fold launches of ONE proof (same unit as `achieved`), from the committed PMC passes of this shape
-                           # (with the first-round fold tables the group streams 34 table rows per point of round 1: ~2.2 GB per proof,
-                           # 0.3 ms at HBM speed, for ~12 ms of ladder arithmetic saved — deliberate traffic, not re-reads)
-                           "traffic": pmc_traffic(["prove2p20/k_ipa_fold_glv<Secq>", "prove2p20/k_ipa_fold_tab<Secq>", "prove2p20/k_ipa_fold_finish<Secq>", "prove2p20/k_ipa_fold_ab<Secq>"],
-                                                  args.logn == 20 and args.curve == 0 and bool(args.fold_tables), "r02_pmc_prove2p20_summary.json", "all_launches"),
+                           "traffic": tr(["prove2p20/k_ipa_fold_glv<Secq>", "prove2p20/k_ipa_fold_tab<Secq>", "prove2p20/k_ipa_fold_finish<Secq>", "prove2p20/k_ipa_fold_ab<Secq>"]),
+                           "traffic_note": "traffic above the algorithmic bytes is deliberate here: ~2.2 GB of table rows streamed by round 1 (instead of 12 ms of ladder "
+                                           "arithmetic) and 0.58 GB of Jacobian results written by the ladders and re-read by k_ipa_fold_finish; together < 0.5 ms at HBM speed",
                            "avg_kernel_ms": fold_ms / max(fold_n, 1), "fold_ms_per_proof": fold_ms,
-                           "msm_kernels_ms_per_proof": msm_ms, "msm_accum_ms_per_proof": acc_ms,
-                           "valu": {"unit": "G modmul/s", "achieved": modmul / per_proof_s / 1e9, "peak": 169.0, "frac": modmul / per_proof_s / 1e9 / 169.0,
-                                    "note": "the path is integer-VALU-bound: this is the fraction that measures the kernels — modular products the fold "
-                                            "launches of one proof need (round 1: fixed-base table look-ups, ~420 per point; later rounds: GLV ladder, ~1950 "
-                                            "per point) against the measured product rate; kernel times are from one proof run alone after the timed region"}}
+                           "msm_kernels_ms_per_proof": msm_ms, "msm_accum_ms_per_proof": acc_all_ms,
+                           "valu": valu_entry(modmul, per_proof_s, "the path is integer-VALU-bound: this is the fraction that measures the kernels — modular products the fold "
+                                              "launches of one proof need (round 1: fixed-base table look-ups; later rounds: GLV ladder, ~1950 per point) against the "
+                                              "ceiling derived from the guide's issue rates; `measured_rate` is what tools/ubench.hip sustains on this GPU"),
+                           "msm_accumulate": {"terms_per_proof": msm_terms, "algorithmic_bytes": 96.0 * msm_terms, "ms": acc_all_ms,
+                                              "hbm_GBps": 96.0 * msm_terms / (acc_all_ms * 1e-3) / 1e9 if acc_all_ms else None,
+                                              "products_upper": msm_terms * madds_per_term * MADD_PRODUCTS,
+                                              "valu_frac_upper": msm_terms * madds_per_term * MADD_PRODUCTS / (acc_all_ms * 1e-3) / 1e9 / VALU_PEAK_GMODMUL if acc_all_ms else None,
+                                              "note": "upper figures: every term costed at the ordinary schedule's %d mixed additions; 7/9 of the terms take the fixed-base schedule (13)" % madds_per_term},
+                           "kernels": kernels}
+    # ---- the same pipeline with the precomputed tables released: what the 150 GB of HBM buy ----
+    if args.tables_off_steps > 0 and (tab_info or msm_tab_info) and not window_sharded:
+        engs[0].set_profiling(False)
+        engs[0].gens_fold_tables(0)
+        engs[0].gens_msm_tables(0)
+        for e in engs[1:]:
+            e.share_gens_from(engs[0])
+        pipe.keep_info = set()
+        pipe.run(101, args.batch, [None] * args.batch)
+        n_off = args.batch * args.tables_off_steps
+        barrier(world)
+        t0 = time.perf_counter()
+        pipe.run(1, n_off, [None] * n_off)
+        barrier(world)
+        dt_off = max_over_ranks(time.perf_counter() - t0, world)
+        res["config"]["tables_off"] = {"value": N * world * n_off / dt_off, "unit": "constraints/s", "steps": args.tables_off_steps, "ms_per_step": dt_off / args.tables_off_steps * 1e3,
+                                       "hbm_spent_on_tables_GB": (tab_info["GB"] if tab_info else 0.0) + (msm_tab_info["GB"] if msm_tab_info else 0.0),
+                                       "note": "same pipeline, same statements family, fold tables and fixed-base MSM rows released"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         res["cpu_baseline"] = cpu_baseline_prove(args)
     for e in engs[1:] + engs[:1]:
@@ -632,10 +763,24 @@ def run_verify(args, rank, world, local):
         # wL/wR/wO read) — 160*N algorithmic bytes per proof; the fused kernel itself reads only the 3.3 KB parameter
         # block per proof and the shared CSC, and writes chunk partials
         nproofs_per_launch = inst.n * steps_profiled[0] / max(vs_n, 1)  # the batch goes through in blocks of 512 proofs, one k_vfy_batch launch each
-        res["roofline"] = {"bound": "hbm", "kernel": "k_vfy_batch (one launch per block of 512 proofs)", "achieved": 160.0 * N * nproofs_per_launch / avg_s / 1e9,
+        cfg4 = args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512 and not shuffle_k
+        traffic = pmc_traffic("verify4096/k_vfy_batch<Secq>", cfg4, "r02_pmc_verify4096_summary.json")
+        # modular products per (proof, element) in k_vfy_batch: 4 split-table look-ups (alpha*a*s_i, b*s_{N-1-i}, alpha*y^-i, alpha*x*y^-i),
+        # z^(q+1) per distinct constraint of the column (~3 for the range-proof gadget: 3.3 with its one non-unit coefficient per bit;
+        # ~2.5 for the shuffle), x*w_L, the g and h products (3), the delta product and its weight: 9 + ~3.3 + 1
+        prod_pe = 13.3 if not shuffle_k else 13.5
+        products = prod_pe * N * nproofs_per_launch
+        tb_ms, tb_n = eng.kernel_time(11)
+        res["roofline"] = {"bound": "hbm", "kernel": "k_vfy_batch (one launch per block of 512 proofs)", "per": "one launch (%d proofs x %d elements)" % (int(nproofs_per_launch), N),
+                           "achieved": 160.0 * N * nproofs_per_launch / avg_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * N * nproofs_per_launch / avg_s / 1e9 / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic("verify4096/k_vfy_batch<Secq>", args.proofs == 4096 and args.curve == 0 and nproofs_per_launch == 512 and not shuffle_k, "r02_pmc_verify4096_summary.json"),
-                           "avg_kernel_ms": vs_ms / vs_n, "algorithmic_bytes_per_verify": per_proof_bytes}
+                           "traffic": traffic,
+                           "traffic_note": "below the algorithmic bytes: the 2N scalars of a proof are never materialised (fused into the alpha-weighted accumulation)",
+                           "avg_kernel_ms": vs_ms / vs_n, "algorithmic_bytes_per_verify": per_proof_bytes,
+                           "valu": valu_entry(products, avg_s, "k_vfy_batch is integer-VALU-bound: ~%.1f modular products per (proof, element) against the ceiling derived "
+                                              "from the guide's issue rates; SQ counters of this kernel: profiles/r0x_sq_vfy_batch_*.txt" % prod_pe),
+                           "kernels": [kernel_entry("k_vfy_batch", vs_ms / vs_n, 1, 160.0 * N * nproofs_per_launch, traffic, products),
+                                       kernel_entry("k_vfy_tables (per-proof split tables)", tb_ms / max(tb_n, 1), 1, None, None, None)]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         from oracle import pyoracle as O
 
@@ -659,8 +804,22 @@ def cpu_baseline_prove(args):
     n = 1 << logn
     pr = O.r1cs_prove(args.curve, O.SC_SQUARE_CHAIN, [n, 0], bytes([3]) * 32, n, m_cap=8)
     assert pr.rc == 0
-    return {"value": n / pr.t_prove, "unit": "constraints/s", "cores": 1, "kind": "port",
-            "sample": "square-chain circuit with 2^%d constraints (prove() only, %.1f s), reference algorithm restated in C++" % (logn, pr.t_prove)}
+    out = {"value": n / pr.t_prove, "unit": "constraints/s", "cores": 1, "kind": "port",
+           "sample": "square-chain circuit with 2^%d constraints (prove() only, %.1f s), reference algorithm restated in C++" % (logn, pr.t_prove)}
+    # the reference's optional `parallel` feature (Cargo.toml:76: rayon over the Pippenger windows of every msm call, nothing else),
+    # restated with OpenMP, on every core this process may use (SURVEY.md §8d asks for it beside the default-features figure)
+    cores = max(1, min(cpu_quota(), 64))
+    if cores > 1:
+        O.set_msm_threads(cores)
+        try:
+            pp = O.r1cs_prove(args.curve, O.SC_SQUARE_CHAIN, [n, 0], bytes([3]) * 32, n, m_cap=8)
+        finally:
+            O.set_msm_threads(1)
+        assert pp.rc == 0 and pp.proof == pr.proof
+        out["all_cores"] = {"value": n / pp.t_prove, "unit": "constraints/s", "cores": cores, "kind": "port",
+                            "sample": "the same statement with the msm windows of every call spread over %d threads (%.1f s): the 2-term msm of each folded "
+                                      "generator dominates and has little to spread" % (cores, pp.t_prove)}
+    return out
 
 
 def cpu_baseline_msm(args, bases, sc):
@@ -673,12 +832,92 @@ def cpu_baseline_msm(args, bases, sc):
             "sample": "%d-term MSM (same bases/scalars), ark window schedule, single thread" % m}
 
 
+def run_shuffle_sweep(args, rank, world, local):
+    """The reference's own benchmark (benches/r1cs_secq256k1.rs:152-189 `bench_kshuffle_prove`, :201-250 `bench_kshuffle_verify`;
+    benches/r1cs_zorro.rs is the same with the zorro types): k-shuffle proof creation and verification for k = 2, 4, ..., 1024,
+    `BulletproofGens::new(2048, 1)`, one proof at a time (criterion times single calls).  Per k and curve: GPU engine (statement
+    construction + prove, as the reference's closure does; Verifier::new + commits + gadget + verify) against the CPU restatement
+    of the reference algorithm on the host's cores.  The k = 2 row on secq256k1 is BASELINE cfg1."""
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+    from oracle import pyoracle as O
+
+    ks = [1 << i for i in range(1, 11)]
+    rows = []
+    reps = max(3, args.steps)
+    for curve in ([args.curve] if args.sweep_one_curve else [0, 1]):
+        eng = A.Engine(curve=curve, device=local)
+        eng.gens_derive(2048)
+        for k in ks:
+            m_cap = 2 * k + 8
+            seed = statement_seed(7, k)
+            for _ in range(max(1, args.warmup)):
+                pr = eng.prove_scenario(E.SC_SHUFFLE, [k], seed, m_cap=m_cap)
+                assert eng.verify_scenario(E.SC_SHUFFLE, [k], pr.proof, pr.commitments, pr.publics) == 0
+            t0 = time.perf_counter()
+            for r in range(reps):
+                pr = eng.prove_scenario(E.SC_SHUFFLE, [k], seed, m_cap=m_cap)
+            t_prove = (time.perf_counter() - t0) / reps
+            t0 = time.perf_counter()
+            for r in range(reps):
+                rc = eng.verify_scenario(E.SC_SHUFFLE, [k], pr.proof, pr.commitments, pr.publics)
+            t_verify = (time.perf_counter() - t0) / reps
+            assert rc == 0
+            row = {"curve": CURVES[curve], "k": k, "multipliers": 2 * (k - 1), "gpu_prove_ms": t_prove * 1e3, "gpu_verify_ms": t_verify * 1e3,
+                   "gpu_prove_inside_prove_ms": pr.timing[0] * 1e3}
+            if not args.no_cpu_baseline:
+                ref = O.r1cs_prove(curve, O.SC_SHUFFLE, [k], seed, 2048, m_cap=m_cap)
+                assert ref.rc == 0 and ref.proof == pr.proof, "GPU proof differs from the CPU restatement's (k = %d)" % k
+                tim = []
+                assert O.r1cs_verify(curve, O.SC_SHUFFLE, [k], 2048, ref.proof, ref.commitments, ref.publics, timing=tim) == 0
+                row.update({"cpu_prove_ms": (ref.t_prove + ref.t_setup) * 1e3, "cpu_prove_inside_prove_ms": ref.t_prove * 1e3, "cpu_verify_ms": tim[0] * 1e3 if tim else None,
+                            "proof_bytes_identical": True})
+            rows.append(row)
+        eng.close()
+    big = [r for r in rows if r["k"] == 1024 and r["curve"] == CURVES[args.curve]][0]
+    return {"metric": "kshuffle_prove_ms (k = 1024; the whole sweep under \"rows\")", "value": big["gpu_prove_ms"], "unit": "ms", "n_gpus": world, "steps": reps, "warmup": args.warmup,
+            "ms_per_step": big["gpu_prove_ms"], "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": "the reference's criterion sweep: k-shuffle prove / verify, k = 2..1024, one proof at a time, BulletproofGens::new(2048, 1) "
+                                   "(benches/r1cs_secq256k1.rs:152-250, benches/r1cs_zorro.rs)", "cfg1": "row k = 2, secq256k1"},
+            "rows": rows,
+            "cpu_baseline": None if args.no_cpu_baseline else {"value": big.get("cpu_prove_ms"), "unit": "ms", "cores": 1, "kind": "port",
+                                                               "sample": "the same k = 1024 statement, reference algorithm restated in C++ (every row carries its own CPU column)"}}
+
+
+def run_cfg5(args, rank, world, local):
+    """BASELINE cfg5 — ONE large proof at a time across all ranks (strong scaling): Pippenger windows of every MSM partitioned
+    across the GPUs with the RCCL point-reduce, the inner-product argument partitioned index-cyclically.  Every
+    rank runs prove() on the same statements and ends with the identical proof."""
+    import copy
+
+    a5 = copy.copy(args)
+    a5.shard, a5.logn = "windows", args.cfg5_logn
+    a5.batch, a5.steps, a5.warmup = 8, max(1, min(args.steps, args.cfg5_steps)), 0       # 8 statements = one lockstep group of the TranscriptRng stage
+    a5.inflight, a5.tables_off_steps, a5.msm_tables = 1, 0, 0
+    a5.window = 8
+    t0 = time.perf_counter()
+    r = run_prove(a5, rank, world, local)
+    out = {"metric": "r1cs_constraints_proved_per_sec", "value": r["value"], "unit": r["unit"], "n_gpus": world, "scaling": "strong", "steps": a5.steps,
+           "ms_per_step": r["ms_per_step"], "ms_per_proof": r["ms_per_step"] / a5.batch, "proofs_per_step": a5.batch,
+           "config": {"workload": "cfg5: 2^%d-constraint R1CS prove, Pippenger windows + index-cyclic IPA partitioned across %d GPUs, %s" % (a5.logn, world, CURVES[args.curve]),
+                      "verified": r["config"]["verified"], "collectives": r["config"]["collectives"], "first_round_fold_tables": r["config"]["first_round_fold_tables"],
+                      "single_proof_latency_ms": r["config"]["single_proof_latency_ms"], "per_proof_stage_ms": r["config"]["per_proof_stage_ms"],
+                      "pipeline_thread_seconds_per_wall_second": r["config"]["pipeline_thread_seconds_per_wall_second"]},
+           "wall_s_including_setup": time.perf_counter() - t0}
+    if "roofline" in r:
+        out["roofline"] = {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "fold_ms_per_proof", "msm_kernels_ms_per_proof") if k in r["roofline"]}
+    return out
+
+
 def run_headline(args, rank, world, local):
-    """both halves of BASELINE.json's metric on one box: prove (top level), then batch verify ("verify")"""
+    """both halves of BASELINE.json's metric on one box: prove (top level), then batch verify ("verify"); with N > 1 ranks also the
+    north_star's partition of one large proof ("cfg5")"""
     res = run_prove(args, rank, world, local)
     ver = run_verify(args, rank, world, local)
     res["metric"] = "r1cs_constraints_proved_per_sec (+ r1cs_batch_verifies_per_sec under \"verify\")"
     res["verify"] = ver
+    if world > 1 and args.cfg5_logn > 0:
+        res["cfg5"] = run_cfg5(args, rank, world, local)
     return res
 
 
@@ -687,7 +926,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm", "shuffle-sweep"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
     ap.add_argument("--verify-inflight", type=int, default=3, help="verify workload: batch_verify calls in flight per GPU (own ctx and host pool each; the pools divide the process's CPU quota)")
@@ -703,6 +942,10 @@ def main():
                     "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s")
     ap.add_argument("--fold-tables", type=int, default=1, help="prove workload: fixed-base tables of the generators for the first fold round (0 = off)")
     ap.add_argument("--msm-tables", type=int, default=1, help="prove workload: fixed-base rows of the generators for the MSMs over the tables themselves (0 = off)")
+    ap.add_argument("--sweep-one-curve", action="store_true", help="shuffle-sweep workload: only --curve (default: secq256k1 and zorro)")
+    ap.add_argument("--cfg5-logn", type=int, default=22, help="headline with --gpus N > 1: size of the window-sharded proofs of the cfg5 leg (0 = skip the leg)")
+    ap.add_argument("--cfg5-steps", type=int, default=2, help="steps (of 8 proofs) of the cfg5 leg")
+    ap.add_argument("--tables-off-steps", type=int, default=4, help="prove workload: timed steps of the same pipeline with the precomputed tables released (0 = skip)")
     ap.add_argument("--fold-table-bits", type=int, default=0, help="window width of those tables (0 = the widest that fits in 3/4 of the free HBM)")
     ap.add_argument("--terms", type=int, default=1 << 16)
     ap.add_argument("--shard", default="terms", choices=["terms", "windows"],
@@ -720,7 +963,7 @@ def main():
         args.host_threads = max(1, int(round(share * 5 / 16)))
     if args.build_threads <= 0:
         args.build_threads = max(2, int(round(share * 8 / 16)))
-    res = {"msm": run_msm, "prove": run_prove, "verify": run_verify, "headline": run_headline}[args.workload](args, rank, world, local)
+    res = {"msm": run_msm, "prove": run_prove, "verify": run_verify, "headline": run_headline, "shuffle-sweep": run_shuffle_sweep}[args.workload](args, rank, world, local)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -97,6 +97,21 @@ int bp_ctx_set_window_shard(bp_ctx* ctx, int rank, int world, bp_point_reduce_cb
  * and finish replicated.  Every fold launch then does 1/world of the single-GPU work; proofs stay byte-identical on every rank. */
 typedef int (*bp_allgather_cb)(void* user, const void* send, size_t bytes, void* recv);
 int bp_ctx_set_shard_allgather(bp_ctx* ctx, bp_allgather_cb cb, void* user);
+/* Native collectives: RCCL over xGMI, inside the library (no host callback, no interpreter lock on the data path).
+ * One rank calls bp_rccl_unique_id (ncclGetUniqueId) and hands the 128 bytes to the others through whatever bootstrap the host
+ * has (a torch.distributed broadcast in bench.py; a Rust host would use its own); then EVERY rank calls bp_ctx_rccl_init on its
+ * ctx (ncclCommInitRank: collective, blocks until all ranks arrive).  The ctx is then in the sharded mode of
+ * bp_ctx_set_window_shard with BOTH exchanges served by ncclAllGather on the ctx's stream: the per-MSM point-reduce
+ * (64-byte affine partials, summed on the host: group addition is not an RCCL reduce op) and the one vector gather of the
+ * index-cyclic inner-product argument.  Ranks must issue the same calls in the same order.  The library binds RCCL at run time
+ * (the copy already in the process, else the ROCm installation's); BP_E_HIP with a message when there is none.
+ * bp_ctx_collective_stats: number of native collectives since init and the host wall time spent in them. */
+int bp_rccl_unique_id(uint8_t out[128]);
+int bp_ctx_rccl_init(bp_ctx* ctx, const uint8_t unique_id[128], int rank, int world);
+int bp_ctx_rccl_shutdown(bp_ctx* ctx);
+int bp_ctx_collective_stats(bp_ctx* ctx, uint64_t* count, double* seconds);
+/* test hook: one native all-gather of `bytes` bytes per rank (recv: world x bytes) */
+int bp_debug_rccl_allgather(bp_ctx* ctx, const uint8_t* send, size_t bytes, uint8_t* recv);
 
 /* ---- InnerProductProof::create -------------------------------------------------------------------
  * Replaces `InnerProductProof::create(transcript, &Q, &G_factors, &H_factors, G_vec, H_vec, a_vec, b_vec)`
@@ -364,7 +379,13 @@ int bp_r1cs_batch_verify_scenarios(bp_ctx* ctx, size_t count, const int* scenari
 #define BP_K_IPA_FOLD 3    /* k_ipa_fold_ab + k_ipa_fold_pts of one round */
 #define BP_K_R1CS_POLY 4   /* k_r1cs_poly_t / k_r1cs_poly_eval */
 #define BP_K_VFY_SCALARS 5 /* k_vfy_scalars */
-#define BP_K_COUNT 8
+#define BP_K_FOLD_TAB 6     /* k_ipa_fold_tab: the first fold round through the fixed-base tables */
+#define BP_K_FOLD_LADDER 7  /* k_ipa_fold_glv / k_ipa_fold_uniform / k_ipa_fold_pts: the scalar-multiplication ladders of a round */
+#define BP_K_FOLD_FINISH 8  /* k_ipa_fold_finish: Jacobian -> affine with shared inversions */
+#define BP_K_MSM_ACCUM_FS 9 /* k_msm_accum_fs: accumulate of the fixed-shape pipeline (mid-size MSMs) */
+#define BP_K_MSM_AGG 10     /* bucket reduction + aggregation (k_msm_reduce*, k_msm_marginals*, k_msm_window_sums) */
+#define BP_K_VFY_TABLES 11  /* k_vfy_tables */
+#define BP_K_COUNT 12
 int bp_ctx_set_profiling(bp_ctx* ctx, int enabled);
 /* accumulated milliseconds and launch count since the last reset */
 int bp_ctx_kernel_time(bp_ctx* ctx, int which, double* ms_total, uint64_t* launches);

@@ -70,6 +70,9 @@ static const BulletproofGens& gens_for(int curve, size_t cap) {
 extern "C" {
 
 int orc_init() { init_once(); return 0; }
+// threads over the Pippenger windows of every msm call (the reference's `parallel` feature, Cargo.toml:76); 1 = default features
+void orc_set_msm_threads(int n) { Curve::msm_threads() = n < 1 ? 1 : n; }
+int orc_get_msm_threads() { return Curve::msm_threads(); }
 
 // ---- field primitives: fid = 2*curve + (0: Fq base field, 1: Fr scalar field) ---------------
 void orc_fe_modulus(int fid, u64* out) { memcpy(out, field_of(fid).p, 32); }

@@ -156,6 +156,8 @@ struct Curve {
     // c = 3 if n < 32 else floor(ceil(log2 n) * 69 / 100) + 2, 2^c bucket slots, running-sum
     // reduction, high->low window combine with c doublings).  The RESULT is a group element and
     // does not depend on this schedule; the schedule is kept for CPU-baseline timing fidelity.
+    // threads over the windows of one msm call (1 = the reference's default features: single-threaded)
+    static int& msm_threads() { static int t = 1; return t; }
     static int ark_window(size_t n) {
         if (n < 32) return 3;
         int lg = 0;
@@ -189,8 +191,8 @@ struct Curve {
             for (int w = 0; w < W; w++) all[i * W + w] = d[w];
         }
         std::vector<Jac> wsum(W);
-        std::vector<Jac> buckets((size_t)1 << c);
-        for (int w = 0; w < W; w++) {
+        // one window: bucket accumulation + running-sum reduction (the closure ark-ec maps over `window_starts`)
+        auto window = [&](int w, std::vector<Jac>& buckets) {
             for (auto& bk : buckets) bk = jac_zero();
             for (size_t i = 0; i < n; i++) {
                 int64_t s = all[i * W + w];
@@ -203,6 +205,20 @@ struct Curve {
                 add(res, res, run);
             }
             wsum[w] = res;
+        };
+        const int nthreads = msm_threads();
+        if (nthreads > 1) {
+            // the reference's optional `parallel` feature (Cargo.toml:76 -> ark-ec/parallel): rayon over the Pippenger WINDOWS of
+            // every msm call, nothing else [3P-mem]; restated with OpenMP for the all-cores CPU baseline
+#pragma omp parallel num_threads(nthreads)
+            {
+                std::vector<Jac> buckets((size_t)1 << c);
+#pragma omp for schedule(static)
+                for (int w = 0; w < W; w++) window(w, buckets);
+            }
+        } else {
+            std::vector<Jac> buckets((size_t)1 << c);
+            for (int w = 0; w < W; w++) window(w, buckets);
         }
         Jac total = jac_zero();
         for (int w = W - 1; w >= 1; w--) {

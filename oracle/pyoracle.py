@@ -46,6 +46,11 @@ def _u64(n):
     return np.zeros(n, dtype=np.uint64)
 
 
+def set_msm_threads(n):
+    """threads over the Pippenger windows of every msm call (the reference's optional `parallel` feature); 1 = its default"""
+    lib().orc_set_msm_threads(int(n))
+
+
 def fid(curve, scalar_field):
     return 2 * curve + (1 if scalar_field else 0)
 

@@ -366,3 +366,34 @@ def test_msm_gens_fixed_base_rows_match_ordinary_schedule(eng, oracle):
     bits = np.array([O.fe_from_int(fr, (i * 7) & 1) for i in range(2 * n)])
     assert (eng.msm_gens(n, bits) == O.msm(cv, np.concatenate([Go, Ho]), bits)).all()
     eng.gens_msm_tables(0)
+
+
+def test_native_rccl_collectives_world_of_one():
+    """bp_rccl_unique_id / bp_ctx_rccl_init / the library's own ncclAllGather (include/arkbp.h "Native collectives") on the one GPU of
+    the test box: the communicator comes up (RCCL bound at run time), an all-gather returns the rank's block, the stats count it,
+    and a ctx with a world-1 communicator still computes the same MSM (nothing to exchange)."""
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+    from oracle import pyoracle as O
+
+    e = A.Engine(curve=0)
+    try:
+        uid = E.rccl_unique_id()
+        assert len(uid) == 128 and any(uid)
+        e.rccl_init(uid, 0, 1)
+        blk = np.arange(96, dtype=np.uint8)
+        out = e.debug_rccl_allgather(blk, 1)
+        assert out.shape == (1, 96) and (out[0] == blk).all()
+        big = (np.arange(1 << 16, dtype=np.uint32) * 2654435761 >> 7).astype(np.uint8)
+        assert (e.debug_rccl_allgather(big, 1)[0] == big).all()
+        n, secs = e.collective_stats()
+        assert n == 2 and secs > 0
+        G, H = O.bp_gens(0, 64)
+        bases = np.concatenate([G, H])
+        sc = O.fe_rand(O.fid(0, True), bytes([12]) * 32, 128)
+        assert (e.msm(bases, sc) == O.msm(0, bases, sc)).all()
+        e.rccl_shutdown()
+        with pytest.raises(E.ArkbpError):
+            e.debug_rccl_allgather(blk, 1)
+    finally:
+        e.close()
