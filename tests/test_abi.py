@@ -106,3 +106,14 @@ def test_bench_gpus_flag_spawns_ranks(monkeypatch):
     cmd = seen["cmd"]
     assert "torch.distributed.run" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4" and "127.0.0.1" in cmd
     assert cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+
+
+def test_rust_ffi_is_generated_from_the_header(lib):
+    """shim/src/ffi.rs (the Rust `extern "C"` block a maintainer of the reference would bind) is exactly what tools/gen_rust_ffi.py
+    makes of include/arkbp.h, and names every exported entry point"""
+    import subprocess
+    import sys
+
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py")], capture_output=True, text=True, check=True).stdout
+    assert gen == open(os.path.join(ROOT, "shim", "src", "ffi.rs")).read(), "run: python tools/gen_rust_ffi.py > shim/src/ffi.rs"
+    assert sorted(re.findall(r"pub fn (bp_\w+)", gen)) == sorted(lib.EXPORTS)

@@ -151,3 +151,44 @@ def test_product_glv_decomposition():
         assert (t1 + lam * t2 - t) % r == 0
     masks = np.zeros(20, dtype=np.uint32)
     assert L.bp_debug_glv_decompose(1, _lib.ptr(tm), _lib.ptr(masks), _lib.ptr(lam_out)) != 0   # zorro: no endomorphism
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_product_transcript_rng_matches_independent_model(E, curve):
+    """the PRODUCT's TranscriptRng (csrc/host_proto.hpp, scalar path and the AVX-512 x8 lockstep path) against the independent
+    STROBE model of tests/pystrobe.py — no oracle involved"""
+    import pystrobe as PS
+
+    p = [0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F, (1 << 255) - 19][curve]
+    R = 1 << 256
+    wit_int = [7, 1 << 200, p - 2]
+    witness = np.array([[(v * R % p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in wit_int], dtype=np.uint64)
+
+    def model(seed, count):
+        tm = PS.Transcript(b"rng pin")
+        b = tm.build_rng()
+        for v in wit_int:
+            b.rekey_with_witness_bytes(b"v_blinding", v.to_bytes(32, "little"))
+        rng = b.finalize(PS.chacha20_block(seed, 0)[:32])
+        out = []
+        while len(out) < count:
+            limbs = [rng.next_u64() for _ in range(4)]
+            limbs[3] &= (1 << (64 - (256 - p.bit_length()))) - 1
+            v = sum(l << (64 * i) for i, l in enumerate(limbs))
+            if v < p:
+                out.append(v)
+        return out
+
+    def ints(rows):
+        return [sum(int(r[i]) << (64 * i) for i in range(4)) for r in rows]
+
+    seed = bytes([33]) * 32
+    got = E.debug_rng_draws(curve, E.HostTranscript(b"rng pin"), witness, seed, 5)
+    assert ints(got[0]) == model(seed, 5)
+    seeds8 = b"".join(bytes([40 + j]) * 32 for j in range(8))
+    got8 = E.debug_rng_draws(curve, E.HostTranscript(b"rng pin"), witness, seeds8, 12)
+    if got8 is not None:      # AVX-512 hosts: the x8 stream yields raw (unrejected) limb groups; every accepted one must be the model's next value
+        for j in range(8):
+            exp = model(seeds8[32 * j: 32 * j + 32], 12)
+            vals = [v for v in ints(got8[j]) if v < p]
+            assert vals[: len(vals)] == exp[: len(vals)] and len(vals) >= 10

@@ -195,3 +195,100 @@ def test_reference_held_constants(oracle):
         b = [O.fe_from_int(f, v) for v in (2, 3, 4, 5)]
         assert (O.inner_product(f, a, b) == O.fe_from_int(f, 40)).all()
     assert O.modulus(O.fid(0, False)) == 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141   # secp256k1's group order
+
+
+# ---- more pins: published vectors for non-zero seeds and later blocks, an independent model of merlin's
+# ---- TranscriptRng, the ark-serialize sign-flag rule at its edges -------------------------------------------------------------
+RFC7539_A1 = [
+    # (key, block counter, first 32 keystream bytes) — RFC 7539 Appendix A.1 test vectors 1-4 (all-zero nonce); rand_chacha 0.3's own
+    # `test_chacha_true_values_a/b/c` are these blocks read as u32 words
+    (bytes(32), 0, "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"),
+    (bytes(32), 1, "9f07e7be5551387a98ba977c732d080dcb0f29a048e3656912c6533e32ee7aed"),
+    (bytes(31) + b"\x01", 1, "3aeb5224ecf849929b9d828db1ced4dd832025e8018b8160b82284f3c949aa5a"),
+    (b"\x00\xff" + bytes(30), 2, "72d54dfbf12ec44b362692df94137f328fea8da73990265ec1bbbea1ae9af0ca"),
+]
+
+
+def test_chacha20_rfc7539_vectors_nonzero_seed_and_later_blocks(oracle):
+    """ChaCha20Rng::from_seed(key) read sequentially = the RFC's keystream with the 64-bit block counter starting at 0
+    (`set_word_pos(16 * block)` of rand_chacha's tests = skipping whole blocks); also pins the independent Python block function"""
+    import pystrobe as PS
+
+    for key, block, head in RFC7539_A1:
+        words = oracle.chacha20_words(key, 16 * (block + 1)).tobytes()
+        assert words[64 * block: 64 * block + 32].hex() == head
+        assert PS.chacha20_block(key, block)[:32].hex() == head
+    # a longer run against the independent block function: 40 blocks of a dense key (the counter carries nowhere near 2^32 here)
+    key = bytes(range(1, 33))
+    ks = oracle.chacha20_words(key, 16 * 40).tobytes()
+    assert ks == b"".join(PS.chacha20_block(key, b) for b in range(40))
+
+
+def test_python_strobe_model_is_pinned(oracle):
+    """the model of tests/pystrobe.py reproduces SHA3-512 (its Keccak-f) and merlin's two published transcript vectors"""
+    import pystrobe as PS
+
+    for n in (0, 1, 71, 72, 73, 200):
+        m = bytes((3 * i + 1) & 255 for i in range(n))
+        assert PS.sha3_512(m) == hashlib.sha3_512(m).digest()
+    t = PS.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    t = PS.Transcript(b"test protocol")
+    t.append_message(b"step1", b"some data")
+    data = bytes([99]) * 1024
+    for _ in range(32):
+        chl = t.challenge_bytes(b"challenge", 32)
+        t.append_message(b"bigdata", data)
+        t.append_message(b"challengedata", chl)
+    assert chl.hex() == "a8c933f54fae76e3f9bea93648c1308e7dfa2152dd51674ff3ca438351cf003c"
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_transcript_rng_matches_independent_model(oracle, curve):
+    """merlin's TranscriptRng as the prover uses it (src/r1cs/prover.rs:483-513): build_rng, one rekey_with_witness_bytes per
+    blinding ("v_blinding", 32 canonical bytes), finalize with 32 bytes of the external ChaCha20 rng, then Fr::rand draws
+    (4 x next_u64, top limb masked, rejection) — the oracle against the independent STROBE model"""
+    import pystrobe as PS
+
+    O = oracle
+    FR = O.fid(curve, True)
+    p = O.modulus(FR)
+    witness = O.fe_rand(FR, bytes([21]) * 32, 3)
+    seed = bytes([9 + curve]) * 32
+    to = O.Transcript(b"rng pin")
+    to.append_u64(b"m", 3)
+    got = to.rng_draws(curve, witness, seed, 6)
+    tm = PS.Transcript(b"rng pin")
+    tm.append_u64(b"m", 3)
+    b = tm.build_rng()
+    for w in witness:
+        b.rekey_with_witness_bytes(b"v_blinding", O.fe_to_int(FR, w).to_bytes(32, "little"))
+    rng = b.finalize(PS.chacha20_block(seed, 0)[:32])       # ChaCha20Rng(seed).fill_bytes(32) = the first 32 keystream bytes
+    exp = []
+    while len(exp) < 6:
+        limbs = [rng.next_u64() for _ in range(4)]
+        limbs[3] &= (1 << (64 - (256 - p.bit_length()))) - 1
+        v = sum(l << (64 * i) for i, l in enumerate(limbs))
+        if v < p:
+            exp.append(v)            # the accepted limbs ARE the Montgomery representation
+    assert [O.limbs_to_int(x) for x in got] == exp
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_sign_flag_rule_at_its_edges(oracle, curve):
+    """ark-serialize's SWFlags::from_y_coordinate: flag 0x80 iff y > -y as canonical integers; y = 0 (equal to its negation) and
+    y = (q-1)/2 are "positive" (flag 0), y = (q+1)/2 is "negative".  Serialisation does not validate, so synthetic coordinates
+    reach the rule's edges (no such point is on either curve: both have prime order)."""
+    O = oracle
+    FQ = O.fid(curve, False)
+    q = O.modulus(FQ)
+    x = O.fe_from_int(FQ, 5)
+    for y, flag in ((0, 0x00), (1, 0x00), ((q - 1) // 2, 0x00), ((q + 1) // 2, 0x80), (q - 1, 0x80)):
+        pt = np.concatenate([x, O.fe_from_int(FQ, y)])
+        if y == 0:
+            pt[4:] = 0
+            pt[0] |= np.uint64(0)        # (x, 0) with x != 0 is not the identity encoding
+        unc = O.point_ser(curve, pt, False)
+        assert unc[64] == flag, (y, unc[64])
+        assert O.point_ser(curve, pt, True)[32] == flag
