@@ -199,6 +199,7 @@ struct bp_ctx {
     size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
     size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
     size_t tune_host_threads = 0;                  // BP_TUNE_HOST_THREADS: size of this ctx's host pool (0 = host_pool_threads())
+    size_t tune_msm_glv_min = 256;                 // BP_TUNE_MSM_GLV_MIN: terms from which an MSM on a GLV curve splits its scalars
     DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
     // fixed-base MSM rows of the generators (bp_gens_msm_tables): row r of a table = 2^(4r) * base, r < FB_ROWS, layout [r][i]
     DevBuf fb_G, fb_H, fb_pc;
@@ -303,6 +304,145 @@ static MsmPlan msm_plan(size_t n, int bits) {
     return pl;
 }
 
+// quad-cooperative additions in the latency-bound kernels of the fixed-shape pipeline (ecq.cuh); ARKBP_MSM_NOQUAD=1 restores the
+// lane-per-addition kernels (A/B: profiles/r03_msm_quad_ab.txt)
+static bool msm_use_quad() { static const bool off = getenv("ARKBP_MSM_NOQUAD") != nullptr; return !off; }
+#define MSM_REDUCE_FS_KERNEL(red_g) ((msm_use_quad() && (red_g) == 4u) ? k_msm_reduce_fs<C, true> : k_msm_reduce_fs<C, false>)
+#define MSM_MARGINALS_FS_KERNEL (msm_use_quad() ? k_msm_marginals_fs<C, 256, true> : k_msm_marginals_fs<C, 256, false>)
+// ---- the fixed-shape pipeline over GLV-split scalars (msm.cuh "GLV split"): 2n half-terms of 128 bits ------------------------------
+// Same five launches as the fixed-shape pipeline in msm_run; what changes is the plan — half the windows, hence half the buckets
+// for the reduction / aggregation trees and half the doublings (and marginal sums) of the host's Horner tail.  *done = false when it
+// does not apply or a region overflowed (skewed scalars): the caller then runs the ordinary schedule, which recomputes everything.
+template <class C> static int msm_run_fs_glv(bp_ctx* ctx, const BaseSegs& segs_in, const ScalSegs& d_scalars, size_t n, int scalars_mont, J4& result, bool& done) {
+    typedef host::Grp<C> G;
+    done = false;
+    if constexpr (!C::HAS_GLV) { (void)ctx; (void)segs_in; (void)d_scalars; (void)n; (void)scalars_mont; (void)result; return BP_OK; }
+    else {
+    hipStream_t st = ctx->stream;
+    constexpr int BITS = 128;                       // magnitudes of the halves (glv_split guarantees < 2^128 or flags the MSM)
+    const size_t ne = 2 * n;                        // half-terms
+    MsmPlan pl = msm_plan(ne, BITS);
+    pl.n = (u32)n;                                  // scalars the partition kernel reads
+    if (pl.W > MSM_MAXW || pl.B >= ctx->tune_msm_wsum_min) return BP_OK;
+    const int bits_last = BITS - pl.c * (pl.W - 1);
+    const int wbn = bits_last < pl.c - 1 ? pl.W - 1 : pl.W;
+    if (wbn <= 0) return BP_OK;
+    BinPlan bp; memset(&bp, 0, sizeof bp);
+    {
+        u32 nbin = 1, lg = 0;
+        while ((size_t)nbin * 8192 < ne && nbin < (u32)pl.NB) { nbin <<= 1; lg++; }
+        int LB = pl.c - 1 - (int)lg;
+        while (LB > 11) { nbin <<= 1; LB--; }
+        const double mu = (double)ne / nbin;
+        const size_t cap = std::min<size_t>(ne, (size_t)(mu + 8.0 * std::sqrt(mu) + 64.0));
+        const size_t lds_sort = (((size_t)1 << LB) + 8 + cap) * 4;
+        if (!(ne < ((size_t)1 << (30 - LB)) && lds_sort <= 64 * 1024 && (size_t)wbn * nbin * cap < ((size_t)1 << 31))) return BP_OK;
+        bp.LB = (u32)LB; bp.NBIN = nbin; bp.cap = (u32)cap; bp.wb = (u32)wbn; bp.glv = 1;
+        bp.tpt = (u32)std::min<size_t>(16, std::max<size_t>(1, n / (256 * 512)));
+        if (wbn < pl.W) {
+            const size_t nb_top = std::min<size_t>((size_t)pl.NB, ((size_t)1 << std::max(bits_last, 0)) + 1);
+            if (nb_top > 2049) return BP_OK;   // (k_msm_marginals_fs holds top_nb + 1 prefix counts in 2052 words)
+            bp.top_nb = (u32)nb_top;
+        }
+    }
+    if (!(bp.wb == (u32)pl.W || bp.top_nb > 0) || (size_t)bp.wb * bp.NBIN + 1 > MSM_FS_MAXBINS) return BP_OK;
+    // slots of the narrow top window: the halves are not uniform below 2^128 (|k2| reaches 1.27 * 2^127, |k1| 1.08 * 2^127), so its
+    // low buckets are fuller than a uniform spread: four times the mean
+    SlotPlan sp; memset(&sp, 0, sizeof sp);
+    size_t nslots = (size_t)bp.wb * bp.NBIN * bp.cap;
+    for (int w = (int)bp.wb; w < pl.W; w++) {
+        const size_t cap = std::min<size_t>(ne, 4 * ((ne + bp.top_nb - 1) / bp.top_nb) + 64);
+        sp.base[w] = (u32)nslots; sp.cap[w] = (u32)cap;
+        nslots += (size_t)bp.top_nb * cap;
+    }
+    const int chl_fs = MSM_CHL_BINNED;
+    FsPlan fp; memset(&fp, 0, sizeof fp);
+    fp.has_top = bp.wb < (u32)pl.W ? 1u : 0u;
+    fp.nbins = bp.wb * bp.NBIN + fp.has_top;
+    if (fp.has_top) { u32 t = bp.top_nb; while (t) { fp.top_bits++; t >>= 1; } }
+    const size_t nwin = (size_t)pl.W;
+    const u32 red_g = (size_t)bp.wb * pl.NB > 49152 ? 1u : 4u;
+    const size_t maxch = ((ne * nwin) >> chl_fs) + std::min<size_t>(ne * nwin, nwin * (size_t)pl.NB) + 64;
+    fp.max_chunks = (u32)maxch;
+    fp.top_parts = (u32)std::min<size_t>(MSM_TOP_PARTS_MAX, std::max<size_t>(4, ne >> 15));
+    const size_t tc = (size_t)bp.wb * pl.c + (size_t)fp.top_bits * fp.top_parts;
+    const size_t tb = tc * 96 + 64;
+    if (nslots >= ((size_t)1 << 32) || maxch >= ((size_t)1 << 31)) return BP_OK;
+    constexpr int NL = MSM_NLMAX;
+    BPCHK(ctx->canon.ensure(n * MSM_GLV_WORDS * 4));
+    BPCHK(ctx->hist.ensure_zeroed((size_t)pl.B * 4, st));
+    BPCHK(ctx->totals.ensure_zeroed((NL + 2) * 4 + 4096, st));
+    BPCHK(ctx->slots.ensure(nslots * 4));
+    BPCHK(ctx->bin_cur.ensure_zeroed((size_t)pl.W * bp.NBIN * 4, st));
+    BPCHK(ctx->boff.ensure((size_t)pl.B * 4));
+    BPCHK(ctx->fs_bcnt.ensure((size_t)pl.B * 4));
+    BPCHK(ctx->fs_loff.ensure((size_t)pl.B * 4));
+    BPCHK(ctx->fs_binch.ensure((MSM_FS_MAXBINS + 1) * 4));
+    BPCHK(ctx->fs_sums.ensure((size_t)bp.wb * pl.NB * 96));
+    BPCHK(ctx->lvA.ensure(maxch * 96));
+    BPCHK(ctx->Tbuf.ensure(tb));
+    if (ctx->h_T_cap < tb) {
+        if (ctx->h_T) HIPCHK(hipHostFree(ctx->h_T));
+        HIPCHK(hipHostMalloc((void**)&ctx->h_T, tb + 4096));
+        ctx->h_T_cap = tb + 4096;
+    }
+    BaseSegs segs = segs_in;
+    segs.glv = 1;
+    ScopedK total(ctx, BP_K_MSM_TOTAL);
+    u32* d_over = ctx->totals.as<u32>() + (NL + 1);
+    u32* d_info = ctx->Tbuf.as<u32>() + tc * 24;
+    const int wg = std::max(1, (int)(12288 / bp.NBIN));
+    const u32 gp = (u32)((n + (size_t)256 * bp.tpt - 1) / ((size_t)256 * bp.tpt));
+    for (int wa = 0; wa < (int)bp.wb; wa += wg) {
+        const int we = std::min<int>((int)bp.wb, wa + wg);
+        hipLaunchKernelGGL(k_msm_bin_partition<C>, dim3(gp), dim3(256), ((size_t)(we - wa) * bp.NBIN + (wa == 0 ? bp.top_nb : 0)) * 4, st, d_scalars, ctx->canon.as<u32>(),
+                           ctx->hist.as<u32>(), pl, scalars_mont, bp, sp, ctx->bin_cur.as<u32>(), ctx->slots.as<u32>(), d_over, wa, we, wa == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_msm_bin_sort_fs, dim3(bp.NBIN, bp.wb + fp.has_top), dim3(256), (((size_t)1 << bp.LB) + 8 + bp.cap) * 4, st, ctx->slots.as<u32>(),
+                       ctx->bin_cur.as<u32>(), ctx->hist.as<u32>(), ctx->boff.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(), ctx->fs_binch.as<u32>(),
+                       d_over, pl, bp, sp, chl_fs);
+    {
+        ScopedK acc(ctx, BP_K_MSM_ACCUM_FS);
+        hipLaunchKernelGGL(k_msm_accum_fs<C>, dim3((u32)((maxch + 255) / 256)), dim3(256), 0, st, segs, ctx->slots.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+                           ctx->boff.as<u32>(), ctx->fs_binch.as<u32>(), ctx->lvA.as<u32>(), pl, bp, fp, chl_fs, d_info);
+    }
+    {
+        ScopedK agg(ctx, BP_K_MSM_AGG);
+        hipLaunchKernelGGL(MSM_REDUCE_FS_KERNEL(red_g), dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+                           ctx->fs_binch.as<u32>(), ctx->fs_sums.as<u32>(), pl, bp, fp, chl_fs, red_g);
+        hipLaunchKernelGGL(MSM_MARGINALS_FS_KERNEL, dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+                           ctx->Tbuf.as<u32>(), pl, bp, fp, chl_fs, d_info, d_over);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tb, hipMemcpyDeviceToHost, st));
+    total.stop();
+    HIPCHK(ctx_stream_wait(ctx));
+    HIPCHK(hipGetLastError());
+    const u32* info = (const u32*)((const uint8_t*)ctx->h_T + tc * 96);
+    static const bool mtrace = getenv("ARKBP_MSM_TRACE") != nullptr;
+    if (info[2] != 0) {
+        if (mtrace) fprintf(stderr, "[msm-glv] n=%zu: overflow, the ordinary schedule takes over\n", n);
+        return BP_OK;
+    }
+    J4 acc = G::inf();
+    const u64* T = (const u64*)ctx->h_T;
+    auto add_T = [&](size_t idx) {
+        const u64* t = T + idx * 12;
+        J4 p; memcpy(p.X.v, t, 32); memcpy(p.Y.v, t + 4, 32); memcpy(p.Z.v, t + 8, 32);
+        if (!p.Z.is_zero()) acc = G::add(acc, p);
+    };
+    const int ngen = (int)bp.wb * pl.c;
+    for (int j = ngen + (int)fp.top_bits - 1; j >= 0; j--) {
+        acc = G::dbl(acc);
+        if (j >= ngen) { for (u32 q = 0; q < fp.top_parts; q++) add_T((size_t)ngen + (size_t)(j - ngen) * fp.top_parts + q); }
+        else add_T((size_t)j);
+    }
+    result = acc;
+    done = true;
+    if (mtrace) fprintf(stderr, "[msm-glv] n=%zu c=%d W=%d bins=%u chunks=%u/%u  marginals=%zu\n", n, pl.c, pl.W, fp.nbins, info[0], fp.max_chunks, tc);
+    return BP_OK;
+    }
+}
+
 template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u32* d_scalars_one, size_t n, int scalars_mont, J4& result,
                                       int w_lo = 0, int w_hi = -1 /* window range for multi-GPU window sharding; default all */,
                                       int shard_mode = -1 /* -1: the ctx's mode (window partition + reduce when world > 1); 0: none (replicated);
@@ -341,6 +481,15 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         part = G::from_aff(a);
         return BP_OK;
     };
+    if constexpr (C::HAS_GLV) {
+        // mid-size MSMs on a curve with the endomorphism: the fixed-shape pipeline over GLV-split scalars (half the windows)
+        static const bool no_glv = getenv("ARKBP_MSM_NOGLV") != nullptr, no_fs0 = getenv("ARKBP_MSM_NOFS") != nullptr;
+        if (!no_glv && !no_fs0 && !sharded && w_hi < 0 && ctx->shard_world == 1 && !segs.fixed_c4 && n >= std::max<size_t>(ctx->tune_msm_bin_min, ctx->tune_msm_glv_min) && n < ((size_t)1 << 27)) {
+            bool done = false;
+            BPCHK(msm_run_fs_glv<C>(ctx, segs, d_scalars, n, scalars_mont, result, done));
+            if (done) return BP_OK;
+        }
+    }
     if (w_hi >= 0) { pl.w_lo = std::max(0, w_lo); pl.w_hi = std::min(pl.W, w_hi); }
     if (pl.w_lo >= pl.w_hi) return finish_sharded(result);  // this rank owns no window: the identity
     constexpr int NL = MSM_NLMAX;
@@ -509,9 +658,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
             }
             {
             ScopedK agg(ctx, BP_K_MSM_AGG);
-            hipLaunchKernelGGL(k_msm_reduce_fs<C>, dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+            hipLaunchKernelGGL(MSM_REDUCE_FS_KERNEL(red_g), dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                                ctx->fs_binch.as<u32>(), ctx->fs_sums.as<u32>(), pl, bp, fp, chl_fs, red_g);
-            hipLaunchKernelGGL((k_msm_marginals_fs<C, 256>), dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+            hipLaunchKernelGGL(MSM_MARGINALS_FS_KERNEL, dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                            ctx->Tbuf.as<u32>(), pl, bp, fp, chl_fs, d_info, d_over);
             }
             HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tb, hipMemcpyDeviceToHost, st));
@@ -2030,6 +2179,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
         case BP_TUNE_MSM_BIN_MIN: c->tune_msm_bin_min = (size_t)value; return BP_OK;
         case BP_TUNE_IPA_FREEZE_LEN: c->tune_ipa_freeze_len = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_WSUM_MIN: c->tune_msm_wsum_min = (size_t)value; return BP_OK;
+        case BP_TUNE_MSM_GLV_MIN: c->tune_msm_glv_min = (size_t)value; return BP_OK;
     }
     return BP_E_ARG;
 }

@@ -20,6 +20,7 @@
 // Algorithmic bytes: 96 B per term (64 B affine base + 32 B scalar), SURVEY.md §8(d).
 #pragma once
 #include "ec.cuh"
+#include "ecq.cuh"
 
 namespace arkbp {
 
@@ -44,9 +45,12 @@ struct BaseSegs {
     u32 fixed_c4;                 // window bits / 4 (0 = ordinary MSM)
     u32 tbits;
     u64 row_words[MSM_MAXSEG];
+    // GLV mode (glv_split below): an entry's term field is 2 * term + half; half 1 stands for phi(base) = (beta * x, y)
+    u32 glv;
 };
 __device__ __forceinline__ const u32* seg_base_ptr(const BaseSegs& s, u32 idx) {
     u32 w = 0;
+    if (s.glv) idx >>= 1;
     if (s.fixed_c4) { w = idx >> s.tbits; idx &= (1u << s.tbits) - 1u; }
     int k = 0;
 #pragma unroll
@@ -129,6 +133,111 @@ __device__ __forceinline__ int msm_digit(const u32 k[8], int w, int c, u32& carr
     return (int)d - (int)(carry << c);
 }
 
+// ---- GLV split of an MSM's scalars (curves with the j = 0 endomorphism phi(x, y) = (beta * x, y) = [lambda](x, y): secq256k1) ----
+// s * P = k1 * P + k2 * phi(P) with |k1|, |k2| < 2^128: an n-term MSM over 256-bit scalars becomes a 2n-term MSM over 128-bit ones.
+// The (term, window) work of the accumulate is unchanged; what halves is everything that scales with the number of WINDOWS — the
+// buckets (reduction + aggregation trees) and above all the serial Horner tail on the host (128 doublings instead of 256).
+// Rounded lattice coordinates c1 = (k * G1 + 2^383) >> 384, c2 = (k * G2 + 2^383) >> 384 (G1, G2 = floor(2^384 * b2 / r), floor(2^384 *
+// -b1 / r)); k1 = k - c1 * a1 - c2 * a2, k2 = -c1 * b1 - c2 * b2, evaluated mod 2^160 in two's complement.  |k1| <= (a1 + a2) / 2 + eps
+// < 1.09 * 2^127, |k2| <= (-b1 + b2) / 2 + eps < 1.28 * 2^127 (tools/gen_params.py asserts the basis; tests check 2 * 10^5 scalars
+// against big integers); a magnitude that does not fit 128 bits returns false and the caller takes the ordinary schedule.
+// out: mag1[4] | mag2[4] | signs (bit 0: k1 < 0, bit 1: k2 < 0) | 3 unused words.
+static constexpr int MSM_GLV_WORDS = 12;
+template <class C> __device__ __forceinline__ void glv_mulhi(const u32 k[8], const u32 (&G)[9], u32 c[5]) {
+    u32 acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const u64 t = (u64)k[i] * G[j] + acc[i + j] + carry;
+            acc[i + j] = (u32)t;
+            carry = t >> 32;
+        }
+        acc[i + 9] = (u32)carry;
+    }
+    u64 t = (u64)acc[11] + 0x80000000ull;   // + 2^383: round to nearest
+    u32 cy = (u32)(t >> 32);
+#pragma unroll
+    for (int i = 0; i < 5; i++) { t = (u64)acc[12 + i] + cy; c[i] = (u32)t; cy = (u32)(t >> 32); }
+}
+// acc (5 words, mod 2^160) -= a * b for 5-word a, b (only the columns below 2^160)
+__device__ __forceinline__ void glv_submul5(u32 acc[5], const u32 a[5], const u32 (&b)[5]) {
+    u32 prod[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) prod[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j + i < 5; j++) {
+            const u64 t = (u64)a[i] * b[j] + prod[i + j] + carry;
+            prod[i + j] = (u32)t;
+            carry = t >> 32;
+        }
+    }
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const u64 t = (u64)acc[i] - prod[i] - borrow;
+        acc[i] = (u32)t;
+        borrow = (u32)(t >> 63);
+    }
+}
+__device__ __forceinline__ bool glv_sign_magnitude(u32 v[5], u32& neg) {
+    neg = v[4] >> 31;
+    if (neg) {
+        u32 cy = 1;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { const u64 t = (u64)(~v[i]) + cy; v[i] = (u32)t; cy = (u32)(t >> 32); }
+    }
+    return v[4] == 0;
+}
+template <class C> __device__ __forceinline__ bool glv_split(const u32 k[8], u32 out[MSM_GLV_WORDS]) {
+    u32 c1[5], c2[5];
+    glv_mulhi<C>(k, C::GLV_G1W, c1);
+    glv_mulhi<C>(k, C::GLV_G2W, c2);
+    u32 k1[5], k2[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { k1[i] = k[i]; k2[i] = 0; }
+    glv_submul5(k1, c1, C::GLV_A1W);
+    glv_submul5(k1, c2, C::GLV_A2W);      // k1 = k - c1*a1 - c2*a2
+    glv_submul5(k2, c2, C::GLV_B2W);      // k2 = c1*(-b1) - c2*b2 = -(c2*b2) - (-(c1*nb1)) : two steps
+    {
+        u32 t[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) t[i] = 0;
+        glv_submul5(t, c1, C::GLV_NB1W);  // t = -(c1 * nb1)
+        u32 borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { const u64 d = (u64)k2[i] - t[i] - borrow; k2[i] = (u32)d; borrow = (u32)(d >> 63); }
+    }
+    u32 n1, n2;
+    const bool ok1 = glv_sign_magnitude(k1, n1), ok2 = glv_sign_magnitude(k2, n2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { out[i] = k1[i]; out[4 + i] = k2[i]; }
+    out[8] = n1 | (n2 << 1);
+    out[9] = out[10] = out[11] = 0;
+    return ok1 && ok2;
+}
+__device__ __forceinline__ void load_words12(u32 w[12], const u32* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+}
+__device__ __forceinline__ void store_words12(u32* p, const u32 w[12]) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]); q[2] = make_uint4(w[8], w[9], w[10], w[11]);
+}
+// half h of a split scalar as an 8-word magnitude (upper words zero) and its sign
+__device__ __forceinline__ void glv_half(const u32 g[12], int h, u32 k[8], bool& neg) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { k[i] = h ? g[4 + i] : g[i]; k[4 + i] = 0; }
+    neg = ((g[8] >> h) & 1u) != 0;
+}
+
 // Wave-aggregated counting.  Skewed inputs (the short top window, 0/1 witness vectors, repeated scalars) put
 // most lanes of a wave on the same counter; then one lane adds the whole group's count.  For spread keys the
 // probe (one ballot) fails and every lane issues its own atomic.  Returns this lane's slot when `cursor`.
@@ -204,8 +313,10 @@ struct BinPlan {
     u32 wb;      // windows [0, wb) are binned; [wb, W) use SlotPlan
     u32 tpt;     // terms per lane in k_msm_bin_partition
     u32 top_nb;  // > 0: the slot window has this many possible buckets (<= 2048) and is counted per workgroup in LDS
+    u32 glv;     // the scalars are split (glv_split): every term contributes two half-terms 2 * i, 2 * i + 1 of 128 bits
 };
-// entry in a bin region: (term << (LB+1)) | (fine bucket << 1) | sign
+// entry in a bin region: (term << (LB+1)) | (fine bucket << 1) | sign; with bp.glv the term field is 2 * i + half and `canon` holds
+// MSM_GLV_WORDS words per scalar (the split magnitudes and signs) instead of the 8 canonical words
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_bin_partition(ScalSegs scalars, u32* __restrict__ canon, u32* __restrict__ hist, MsmPlan pl, int scalars_mont, BinPlan bp,
                     SlotPlan sp, u32* __restrict__ bin_cur, u32* __restrict__ ent, u32* __restrict__ overflow, int wa, int we, int first) {
@@ -216,6 +327,7 @@ k_msm_bin_partition(ScalSegs scalars, u32* __restrict__ canon, u32* __restrict__
     const u32 ncnt = nbinc + (top ? bp.top_nb : 0u);
     u32* lds_top = lds_cnt + nbinc;
     const int wtop = pl.W - 1;
+    const int nh = bp.glv ? 2 : 1;
     for (u32 x = threadIdx.x; x < ncnt; x += 256) lds_cnt[x] = 0;
     __syncthreads();
     const u32 tile0 = blockIdx.x * 256u * bp.tpt;
@@ -224,17 +336,31 @@ k_msm_bin_partition(ScalSegs scalars, u32* __restrict__ canon, u32* __restrict__
         const u32 i = tile0 + t * 256u + threadIdx.x;
         if (i >= pl.n) break;
         u32 k[8];
-        load_words8(k, seg_scalar_ptr(scalars, i));
-        if (scalars_mont == 1) { Fe s = fe_load_ark<Fr>(k); fe_store_canon<Fr>(k, s); }
-        else if (scalars_mont == 2) { Fe s = fe_unpack(k); fe_store_canon<Fr>(k, s); }
-        if (first) store_words8(canon + (size_t)i * 8, k);
-        u32 carry = 0;
-        for (int w = 0; w < wend; w++) {
-            const int d = msm_digit(k, w, pl.c, carry);
-            if (d == 0 || w < pl.w_lo || w >= pl.w_hi) continue;
-            const u32 v = (u32)(d < 0 ? -d : d) - 1;
-            if (w >= (int)bp.wb) { if (top && v < bp.top_nb) atomicAdd(&lds_top[v], 1u); }
-            else if (w >= wa && w < we) atomicAdd(&lds_cnt[(u32)(w - wa) * bp.NBIN + (v >> bp.LB)], 1u);
+        u32 g[MSM_GLV_WORDS];
+        if (first) {
+            load_words8(k, seg_scalar_ptr(scalars, i));
+            if (scalars_mont == 1) { Fe s = fe_load_ark<Fr>(k); fe_store_canon<Fr>(k, s); }
+            else if (scalars_mont == 2) { Fe s = fe_unpack(k); fe_store_canon<Fr>(k, s); }
+            if constexpr (C::HAS_GLV) {
+                if (bp.glv) {
+                    if (!glv_split<C>(k, g)) *overflow = 1u;
+                    store_words12(canon + (size_t)i * MSM_GLV_WORDS, g);
+                } else store_words8(canon + (size_t)i * 8, k);
+            } else store_words8(canon + (size_t)i * 8, k);
+        } else {
+            if (bp.glv) load_words12(g, canon + (size_t)i * MSM_GLV_WORDS); else load_words8(k, canon + (size_t)i * 8);
+        }
+        for (int h = 0; h < nh; h++) {
+            bool hneg = false;
+            if (bp.glv) glv_half(g, h, k, hneg);
+            u32 carry = 0;
+            for (int w = 0; w < wend; w++) {
+                const int d = msm_digit(k, w, pl.c, carry);
+                if (d == 0 || w < pl.w_lo || w >= pl.w_hi) continue;
+                const u32 v = (u32)(d < 0 ? -d : d) - 1;
+                if (w >= (int)bp.wb) { if (top && v < bp.top_nb) atomicAdd(&lds_top[v], 1u); }
+                else if (w >= wa && w < we) atomicAdd(&lds_cnt[(u32)(w - wa) * bp.NBIN + (v >> bp.LB)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -248,28 +374,37 @@ k_msm_bin_partition(ScalSegs scalars, u32* __restrict__ canon, u32* __restrict__
         const u32 i = tile0 + t * 256u + threadIdx.x;
         const bool live = i < pl.n;   // no early exit: wave_count below is a wave-wide operation
         u32 k[8];
+        u32 g[MSM_GLV_WORDS];
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = 0;
-        if (live) load_words8(k, canon + (size_t)i * 8);
-        u32 carry = 0;
-        for (int w = 0; w < pl.W; w++) {
-            const int d = msm_digit(k, w, pl.c, carry);
-            const bool valid = live && d != 0 && w >= pl.w_lo && w < pl.w_hi;
-            const u32 v = (u32)(d < 0 ? -d : d) - 1;
-            if (w >= (int)bp.wb) {          // slot scheme (only in the launch that owns the first window group)
-                if (!first) continue;
-                u32 pos;
-                if (bp.top_nb) pos = valid ? atomicAdd(&lds_top[min(v, bp.top_nb - 1u)], 1u) : 0u;
-                else pos = wave_count(hist, (u32)w * pl.NB + v, valid);
-                if (valid) {
-                    if (pos < sp.cap[w]) ent[sp.base[w] + v * sp.cap[w] + pos] = (i << 1) | (d < 0 ? 1u : 0u);
+#pragma unroll
+        for (int j = 0; j < MSM_GLV_WORDS; j++) g[j] = 0;
+        if (live) { if (bp.glv) load_words12(g, canon + (size_t)i * MSM_GLV_WORDS); else load_words8(k, canon + (size_t)i * 8); }
+        for (int h = 0; h < nh; h++) {
+            bool hneg = false;
+            if (bp.glv) glv_half(g, h, k, hneg);
+            const u32 vi = bp.glv ? 2u * i + (u32)h : i;   // term field of the entry
+            u32 carry = 0;
+            for (int w = 0; w < pl.W; w++) {
+                const int d = msm_digit(k, w, pl.c, carry);
+                const bool valid = live && d != 0 && w >= pl.w_lo && w < pl.w_hi;
+                const u32 v = (u32)(d < 0 ? -d : d) - 1;
+                const u32 sign = ((d < 0) != hneg) ? 1u : 0u;
+                if (w >= (int)bp.wb) {          // slot scheme (only in the launch that owns the first window group)
+                    if (!first) continue;
+                    u32 pos;
+                    if (bp.top_nb) pos = valid ? atomicAdd(&lds_top[min(v, bp.top_nb - 1u)], 1u) : 0u;
+                    else pos = wave_count(hist, (u32)w * pl.NB + v, valid);
+                    if (valid) {
+                        if (pos < sp.cap[w] && (!bp.top_nb || v < bp.top_nb)) ent[sp.base[w] + v * sp.cap[w] + pos] = (vi << 1) | sign;
+                        else *overflow = 1u;
+                    }
+                } else if (valid && w >= wa && w < we) {
+                    const u32 bin = v >> bp.LB;
+                    const u32 pos = atomicAdd(&lds_cnt[(u32)(w - wa) * bp.NBIN + bin], 1u);
+                    if (pos < bp.cap) ent[((size_t)w * bp.NBIN + bin) * bp.cap + pos] = (vi << (bp.LB + 1)) | ((v & fmask) << 1) | sign;
                     else *overflow = 1u;
                 }
-            } else if (valid && w >= wa && w < we) {
-                const u32 bin = v >> bp.LB;
-                const u32 pos = atomicAdd(&lds_cnt[(u32)(w - wa) * bp.NBIN + bin], 1u);
-                if (pos < bp.cap) ent[((size_t)w * bp.NBIN + bin) * bp.cap + pos] = (i << (bp.LB + 1)) | ((v & fmask) << 1) | (d < 0 ? 1u : 0u);
-                else *overflow = 1u;
             }
         }
     }
@@ -628,6 +763,36 @@ template <class C, u32 NT = 256> __device__ __forceinline__ Jac block_sum_jac(Ja
     }
     return acc;
 }
+// The same sum with QUAD-COOPERATIVE additions (ecq.cuh): every lane parks its point in LDS, then m points become m/2 per level with
+// one quad (4 lanes, one modular product per lane and dependency level) per addition — a level costs ~3 us instead of ~9 for the
+// lane-per-addition tree above (tools/ubench_coop.hip, profiles/r03_ubench_coop.txt).  Valid in lane 0.
+__device__ __forceinline__ void lds_put_jac(u32* __restrict__ sh, u32 NT, u32 slot, const Jac& a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) { sh[i * NT + slot] = a.X.l[i]; sh[(9 + i) * NT + slot] = a.Y.l[i]; sh[(18 + i) * NT + slot] = a.Z.l[i]; }
+}
+__device__ __forceinline__ Jac lds_get_jac(const u32* __restrict__ sh, u32 NT, u32 slot) {
+    Jac o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { o.X.l[i] = sh[i * NT + slot]; o.Y.l[i] = sh[(9 + i) * NT + slot]; o.Z.l[i] = sh[(18 + i) * NT + slot]; }
+    return o;
+}
+template <class C, u32 NT = 256> __device__ __forceinline__ Jac block_sum_jac_quad(const Jac& acc, u32* __restrict__ sh /* NT * 27 words */) {
+    const u32 tid = threadIdx.x, q = tid & 3u, quad = tid >> 2;
+    lds_put_jac(sh, NT, tid, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (u32 half = NT / 2; half >= 1; half >>= 1) {
+        // pair j = (slot j, slot j + half) -> slot j.  A pass reads only slots its own quad writes or slots no quad of the pass
+        // writes, so the (at most two) passes of a level need no barrier between them.
+#pragma unroll 1
+        for (u32 j = quad; j < half; j += NT / 4) {
+            const Jac r = qjac_add<C>(lds_get_jac(sh, NT, j), lds_get_jac(sh, NT, j + half), q);
+            if (q == 0) lds_put_jac(sh, NT, j, r);
+        }
+        __syncthreads();
+    }
+    return lds_get_jac(sh, NT, 0);
+}
 // a lane's point from `o` lanes further down its group of `width` lanes
 __device__ __forceinline__ Jac jac_shfl_down(const Jac& a, int o, int width = 64) {
     Jac r;
@@ -910,6 +1075,9 @@ k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __rest
                 ent_n = entries[e + 1];
                 p_n = load_aff_dev(seg_base_ptr(segs, ent_n >> 1));
             }
+            if constexpr (C::HAS_GLV) {   // odd half-terms of a split scalar stand for phi(base) = (beta * x, y)
+                if (segs.glv && (ent & 2u) && !aff_is_inf(p)) p.x = fe_mul<typename C::Fq>(p.x, fe_const<typename C::Fq, C::BETA29>());
+            }
             acc = jac_madd<C>(acc, aff_cneg_lazy<C>(p, ent & 1));
             ent = ent_n;
             p = p_n;
@@ -919,7 +1087,7 @@ k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __rest
 }
 // G lanes per bucket of the binned windows (G = 4, or 1 when the buckets alone fill the chip): lane q of the group sums partials
 // q, q + G, .. (<= 2^chl in all), lg G shuffle levels join them -> sums[b] (the identity when the bucket is empty)
-template <class C> __global__ void __launch_bounds__(256)
+template <class C, bool QUAD = false> __global__ void __launch_bounds__(256)
 k_msm_reduce_fs(const u32* __restrict__ part, const u32* __restrict__ bcnt, const u32* __restrict__ loff, const u32* __restrict__ bin_chunks,
                 u32* __restrict__ sums, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32 G) {
     __shared__ u32 base[MSM_FS_MAXBINS + 1];
@@ -933,6 +1101,16 @@ k_msm_reduce_fs(const u32* __restrict__ part, const u32* __restrict__ bcnt, cons
     const u32 first = base[w * bp.NBIN + (v >> bp.LB)] + loff[b];
     u32 nch = min((bcnt[b] + (1u << chl) - 1u) >> chl, 1u << chl);
     if (first + nch > fp.max_chunks) nch = 0;
+    if (QUAD) {
+        // G == 4: the four lanes of a bucket are a DPP quad and SHARE every addition (ecq.cuh): the bucket's <= 16 partials as one
+        // serial chain of quad additions (~3 us each) instead of 1-4 lane additions (~8 us each) plus two shuffle levels
+        Jac acc = jac_inf<C>();
+        if (nch) acc = load_jac_ws(part + (size_t)first * 24);
+#pragma unroll 1
+        for (u32 e = 1; e < nch; e++) acc = qjac_add<C>(acc, load_jac_ws(part + (size_t)(first + e) * 24), q);   // (trip count is quad-uniform)
+        if (q == 0 && gb < nbk) store_jac_ws<C>(sums + (size_t)b * 24, acc);
+        return;
+    }
     // ONE inlined addition serves the serial steps and the shuffle levels: a Jacobian addition is ~50 KB of straight-line code
     Jac acc = jac_inf<C>();
     u32 e = q;
@@ -966,7 +1144,7 @@ template <class C> __device__ __forceinline__ void store_T_ark(u32* __restrict__
 }
 // blocks [0, wb * c): (w, k) of the binned windows over the dense sums; then top_bits * top_parts blocks for the slot window, summing
 // the level-1 partials of the buckets whose value has bit k.  T_out[wb * c + k * top_parts + part]; info[2] = overflow flag (then cleared).
-template <class C, u32 NT> __global__ void __launch_bounds__(NT)
+template <class C, u32 NT, bool QUAD = false> __global__ void __launch_bounds__(NT)
 k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, const u32* __restrict__ bcnt, const u32* __restrict__ loff,
                    u32* __restrict__ T_out, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32* __restrict__ info, u32* __restrict__ overflow) {
     __shared__ u32 pre[2052];      // slot window: prefix counts of the partials of the buckets with bit k (top_nb <= 2048)
@@ -1023,7 +1201,7 @@ k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, c
         if (!__any(src != nullptr)) break;
         if (src) acc = jac_add<C>(acc, load_jac_ws(src));
     }
-    acc = block_sum_jac<C, NT>(acc, tree);
+    acc = QUAD ? block_sum_jac_quad<C, NT>(acc, tree) : block_sum_jac<C, NT>(acc, tree);
     if (tid == 0) store_T_ark<C>(T_out + (size_t)blockIdx.x * 24, acc);
 }
 

@@ -406,6 +406,7 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
 #define BP_TUNE_HOST_THREADS 6    /* host threads of this ctx's pool for the per-instance transcript replays of batch verification (0 = default:
                                      the machine's hardware threads, at most 32, or ARKBP_HOST_THREADS); callers that keep several batches in
                                      flight on several ctxs divide the cores among them */
+#define BP_TUNE_MSM_GLV_MIN 7     /* terms from which a variable-base MSM on secq256k1 splits its scalars with the endomorphism (default 256; a huge value turns it off) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 
 /* The O(N) part of `Verifier::verification_scalars` (src/r1cs/verifier.rs:465-514, s from inner_product_proof.rs:279-311) for a

@@ -397,3 +397,51 @@ def test_native_rccl_collectives_world_of_one():
             e.debug_rccl_allgather(blk, 1)
     finally:
         e.close()
+
+
+def test_msm_glv_split_schedule_matches_ordinary_and_oracle(oracle):
+    """secq256k1's mid-size MSMs split their scalars with the endomorphism (msm.cuh glv_split: s*P = k1*P + k2*phi(P), two
+    128-bit halves): same value as the ordinary schedule (BP_TUNE_MSM_GLV_MIN turns the split off) and as the oracle, for spread
+    scalars and for the scalars where the decomposition is extreme: 0, 1, r-1, (r-1)/2, lambda and lambda^2 (the halves swap roles),
+    2^128 - 1, 2^128, 2^255, duplicates and identity bases, skew that overflows (ordinary schedule takes over)."""
+    import ark_bulletproofs_amd as A
+
+    O, cv = oracle, 0
+    FR = O.fid(cv, True)
+    r = O.modulus(FR)
+    e = A.Engine(curve=cv)
+    try:
+        lam = next(l for l in (pow(g, (r - 1) // 3, r) for g in range(2, 20)) if l != 1)
+        special = [0, 1, 2, r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, lam, lam * lam % r, r - lam, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, 1 << 255, (1 << 127), r // 3, 3]
+        for n in (256, 1000, 5000, 1 << 15):
+            G, H = O.bp_gens(cv, n // 2 + 1)
+            bases = np.concatenate([G, H])[:n]
+            sc = O.fe_rand(FR, bytes([n % 251]) * 32, n)
+            for j, v in enumerate(special):
+                sc[(j * 13) % n] = O.fe_from_int(FR, v)
+            bases[5] = bases[4]
+            bases[9] = 0
+            e.set_tuning(7, 256)
+            got_glv = e.msm(bases, sc)
+            e.set_tuning(7, 1 << 40)
+            got_plain = e.msm(bases, sc)
+            assert (got_glv == got_plain).all(), n
+            if n <= 5000:
+                assert (got_glv == O.msm(cv, bases, sc)).all(), n
+        # the special scalars alone, repeated: every half-term of a window in a handful of buckets
+        n = 1024
+        G, H = O.bp_gens(cv, n)
+        sc = np.array([O.fe_from_int(FR, special[i % len(special)]) for i in range(n)])
+        e.set_tuning(7, 256)
+        assert (e.msm(G, sc) == O.msm(cv, G, sc)).all()
+        # lane-per-addition trees (ARKBP_MSM_NOQUAD has no run-time switch): the quad-cooperative trees are what ran above; the same
+        # inputs through the general path (two-level sort minimum above n) must agree
+        sc = O.fe_rand(FR, bytes([77]) * 32, n)
+        a = e.msm(G, sc)
+        e.set_tuning(1, 1 << 30)
+        e.set_tuning(7, 1 << 40)
+        b = e.msm(G, sc)
+        e.set_tuning(1, 64)
+        assert (a == b).all() and (a == O.msm(cv, G, sc)).all()
+    finally:
+        e.close()
