@@ -306,9 +306,12 @@ static MsmPlan msm_plan(size_t n, int bits) {
 
 // quad-cooperative additions in the latency-bound kernels of the fixed-shape pipeline (ecq.cuh); ARKBP_MSM_NOQUAD=1 restores the
 // lane-per-addition kernels (A/B: profiles/r03_msm_quad_ab.txt)
-static bool msm_use_quad() { static const bool off = getenv("ARKBP_MSM_NOQUAD") != nullptr; return !off; }
-#define MSM_REDUCE_FS_KERNEL(red_g) ((msm_use_quad() && (red_g) == 4u) ? k_msm_reduce_fs<C, true> : k_msm_reduce_fs<C, false>)
-#define MSM_MARGINALS_FS_KERNEL (msm_use_quad() ? k_msm_marginals_fs<C, 256, true> : k_msm_marginals_fs<C, 256, false>)
+static bool msm_use_quad() { static const bool on = getenv("ARKBP_MSM_QUAD") != nullptr; return on; }
+// (direct launches in both branches: a kernel template named only inside a conditional expression is not emitted for the device)
+#define MSM_LAUNCH_REDUCE_FS(red_g, grid, ...) do { if (msm_use_quad() && (red_g) == 4u) hipLaunchKernelGGL((k_msm_reduce_fs<C, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
+                                                    else hipLaunchKernelGGL((k_msm_reduce_fs<C, false>), grid, dim3(256), 0, st, __VA_ARGS__); } while (0)
+#define MSM_LAUNCH_MARGINALS_FS(grid, ...) do { if (msm_use_quad()) hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
+                                                else hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, false>), grid, dim3(256), 0, st, __VA_ARGS__); } while (0)
 // ---- the fixed-shape pipeline over GLV-split scalars (msm.cuh "GLV split"): 2n half-terms of 128 bits ------------------------------
 // Same five launches as the fixed-shape pipeline in msm_run; what changes is the plan — half the windows, hence half the buckets
 // for the reduction / aggregation trees and half the doublings (and marginal sums) of the host's Horner tail.  *done = false when it
@@ -408,9 +411,9 @@ template <class C> static int msm_run_fs_glv(bp_ctx* ctx, const BaseSegs& segs_i
     }
     {
         ScopedK agg(ctx, BP_K_MSM_AGG);
-        hipLaunchKernelGGL(MSM_REDUCE_FS_KERNEL(red_g), dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+        MSM_LAUNCH_REDUCE_FS(red_g, dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                            ctx->fs_binch.as<u32>(), ctx->fs_sums.as<u32>(), pl, bp, fp, chl_fs, red_g);
-        hipLaunchKernelGGL(MSM_MARGINALS_FS_KERNEL, dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+        MSM_LAUNCH_MARGINALS_FS(dim3((u32)tc), ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                            ctx->Tbuf.as<u32>(), pl, bp, fp, chl_fs, d_info, d_over);
     }
     HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tb, hipMemcpyDeviceToHost, st));
@@ -658,9 +661,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
             }
             {
             ScopedK agg(ctx, BP_K_MSM_AGG);
-            hipLaunchKernelGGL(MSM_REDUCE_FS_KERNEL(red_g), dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), dim3(256), 0, st, ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+            MSM_LAUNCH_REDUCE_FS(red_g, dim3((u32)(((size_t)bp.wb * pl.NB * red_g + 255) / 256)), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                                ctx->fs_binch.as<u32>(), ctx->fs_sums.as<u32>(), pl, bp, fp, chl_fs, red_g);
-            hipLaunchKernelGGL(MSM_MARGINALS_FS_KERNEL, dim3((u32)tc), dim3(256), 0, st, ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
+            MSM_LAUNCH_MARGINALS_FS(dim3((u32)tc), ctx->fs_sums.as<u32>(), ctx->lvA.as<u32>(), ctx->fs_bcnt.as<u32>(), ctx->fs_loff.as<u32>(),
                            ctx->Tbuf.as<u32>(), pl, bp, fp, chl_fs, d_info, d_over);
             }
             HIPCHK(hipMemcpyAsync(ctx->h_T, ctx->Tbuf.p, tb, hipMemcpyDeviceToHost, st));

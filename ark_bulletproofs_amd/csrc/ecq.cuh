@@ -15,6 +15,8 @@
 
 namespace arkbp {
 
+#if defined(__HIPCC__)
+#define ARKBP_QD __device__ __forceinline__
 // value of x in lane (quad base + k), for every lane of the quad; k compile-time
 template <int K> __device__ __forceinline__ u32 quad_bcast(u32 x) {
     return (u32)__builtin_amdgcn_update_dpp(0, (int)x, K * 0x55, 0xF, 0xF, false);
@@ -25,8 +27,25 @@ template <int K> __device__ __forceinline__ Fe quad_bcast_fe(const Fe& a) {
     for (int i = 0; i < 9; i++) r.l[i] = quad_bcast<K>(a.l[i]);
     return r;
 }
+#else
+#define ARKBP_QD inline
+// CPU stand-in for the DPP exchange (tests/test_fp29_host.py): the four lanes of a quad run one after the other, several rounds;
+// an exchange site hands out what the lanes stored there in the previous round.  A site's inputs depend only on earlier sites, so
+// after r rounds the first r sites carry the final values — the schedule is checked without a GPU.
+struct QuadSim {
+    Fe slot[32][4];
+    int site = 0, lane = 0;
+};
+inline QuadSim& quad_sim() { static thread_local QuadSim s; return s; }
+template <int K> inline Fe quad_bcast_fe(const Fe& a) {
+    QuadSim& s = quad_sim();
+    const int c = s.site++;
+    s.slot[c][s.lane] = a;
+    return s.slot[c][K];
+}
+#endif
 // this lane's choice among four replicated values by its position in the quad (q = lane & 3)
-__device__ __forceinline__ Fe quad_pick(u32 q, const Fe& a0, const Fe& a1, const Fe& a2, const Fe& a3) {
+ARKBP_QD Fe quad_pick(u32 q, const Fe& a0, const Fe& a1, const Fe& a2, const Fe& a3) {
     Fe r;
     const bool hi = (q & 2u) != 0, odd = (q & 1u) != 0;
 #pragma unroll
@@ -37,7 +56,7 @@ __device__ __forceinline__ Fe quad_pick(u32 q, const Fe& a0, const Fe& a1, const
     }
     return r;
 }
-__device__ __forceinline__ Fe quad_pick2(u32 q, const Fe& a0, const Fe& a1) {   // lanes 0 / 1 (lanes 2, 3 take a0 / a1 as well)
+ARKBP_QD Fe quad_pick2(u32 q, const Fe& a0, const Fe& a1) {   // lanes 0 / 1 (lanes 2, 3 take a0 / a1 as well)
     Fe r;
     const bool odd = (q & 1u) != 0;
 #pragma unroll
@@ -49,7 +68,7 @@ __device__ __forceinline__ Fe quad_pick2(u32 q, const Fe& a0, const Fe& a1) {   
 //   1: A = Z1^2 | B = Z2^2 | D = Y1*Z2 | E = Y2*Z1         2: U1 = X1*B | U2 = X2*A | S1 = D*B | S2 = E*A
 //   3: HH = H^2 | C = Z1*Z2 | rr = r^2 | -                 4: HHH = H*HH | V = U1*HH | Z3 = C*H | -
 //   5: T1 = r*(V - X3) | T2 = S1*HHH | - | -
-template <class C> __device__ __forceinline__ Jac qjac_add(const Jac& p, const Jac& q_, u32 q) {
+template <class C> ARKBP_QD Jac qjac_add(const Jac& p, const Jac& q_, u32 q) {
     typedef typename C::Fq F;
     if (jac_is_inf(q_)) return p;
     if (jac_is_inf(p)) return q_;
@@ -83,7 +102,7 @@ template <class C> __device__ __forceinline__ Jac qjac_add(const Jac& p, const J
 // Jacobian + affine (q.y may be a lazy negation), replicated in / out.
 //   1: A = Z1^2 | E = y2*Z1     2: U2 = x2*A | S2 = E*A     3: HH = H^2 | rr = r^2 | Z3 = Z1*H     4: HHH = H*HH | V = X1*HH
 //   5: T1 = r*(V - X3) | T2 = Y1*HHH
-template <class C> __device__ __forceinline__ Jac qjac_madd(const Jac& p, const Aff& a, u32 q) {
+template <class C> ARKBP_QD Jac qjac_madd(const Jac& p, const Aff& a, u32 q) {
     typedef typename C::Fq F;
     if (aff_is_inf(a)) return p;
     if (jac_is_inf(p)) {
@@ -118,7 +137,7 @@ template <class C> __device__ __forceinline__ Jac qjac_madd(const Jac& p, const 
 // doubling, replicated in / out.
 //   a = 0:  1: A = X^2 | B = Y^2 | Z3' = Y*Z      2: Cc = B^2 | D' = X*B       3: F = E^2 (E = 3A)      4: Y3' = E*(D - X3)
 //   a != 0: 1: XX | YY | ZZ | Z3' = Y*Z           2: YYYY | S' = X*YY | Z4 = ZZ^2   3: F = M^2 (M = 3XX + a*Z4)   4: Y3' = M*(S - X3)
-template <class C> __device__ __forceinline__ Jac qjac_dbl(const Jac& p, u32 q) {
+template <class C> ARKBP_QD Jac qjac_dbl(const Jac& p, u32 q) {
     typedef typename C::Fq F;
     if (jac_is_inf(p)) return p;
     Jac o;
@@ -152,6 +171,7 @@ template <class C> __device__ __forceinline__ Jac qjac_dbl(const Jac& p, u32 q) 
     return o;
 }
 
+#if defined(__HIPCC__)
 // ---- limb-per-lane Montgomery product (the north_star's layout) ------------------------------------------------------------
 // Lane j (j = 0..8) of a 16-lane row holds limb j of a and of b; lanes 9..15 of the row hold zeros.  Operand scanning: step i adds
 // a_i * b_j into column accumulator j (a_i broadcast through the row: ds_swizzle — gfx9 DPP has no row_share), lane 0's column
@@ -194,5 +214,7 @@ template <class P> __device__ __forceinline__ u32 fe_mul_limblane(u32 a_j, u32 b
     }
     return (u32)acc;
 }
+
+#endif  // __HIPCC__ (the limb-per-lane product exists on the device only)
 
 }  // namespace arkbp

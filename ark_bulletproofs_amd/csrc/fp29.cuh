@@ -15,6 +15,7 @@
 // Contracts (checked on the CPU by tests/test_fp29_host.py through csrc/fp29_selftest.cpp when
 // ARKBP_CHECK_BOUNDS is defined).  L = largest limb / 2^29, V = value / p:
 //   fe_mul / fe_sqr   in: L(a)*L(b) <= 6, V(a)*V(b) <= 900   out: L = 1, V < V(a)V(b)/32 + 1
+//   fe_mul2           a*b + c*d, one reduction: L(a)L(b) + L(c)L(d) <= 6, V(a)V(b) + V(c)V(d) <= 900; out as fe_mul
 //   fe_add            limb-wise, no carry                    out: L = La + Lb, V = Va + Vb
 //   fe_sub<K>         in: L(a) <= 2, L(b) < 4, V(b) < K      out: L = 1, V = Va + K
 //   fe_norm           carry pass                              out: L = 1
@@ -151,6 +152,42 @@ template <class P> ARKBP_HD Fe fe_mul(const Fe& a, const Fe& b) {
         acc >>= 29;
     }
     ARKBP_ASSERT(acc < (1ull << 29), "fe_mul: result exceeds 2^261");
+    t.l[8] = (u32)acc;
+    return t;
+}
+
+// a*b + c*d with ONE Montgomery reduction: (a*b + c*d) / 2^261 mod p.  243 limb products instead of 324 for two products and an
+// addition.  in: L(a)*L(b) + L(c)*L(d) <= 6 (a column holds 9 + 9 operand products and 9 reduction products in 64 bits),
+// V(a)V(b) + V(c)V(d) <= 900; out: L = 1, V < (V(a)V(b) + V(c)V(d)) / 32 + 1.
+template <class P> ARKBP_HD Fe fe_mul2(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
+#ifdef ARKBP_CHECK_BOUNDS
+    { u64 la = 0, lb = 0, lc = 0, ld = 0;
+      for (int i = 0; i < 9; i++) { if (a.l[i] > la) la = a.l[i]; if (b.l[i] > lb) lb = b.l[i]; if (c.l[i] > lc) lc = c.l[i]; if (d.l[i] > ld) ld = d.l[i]; }
+      ARKBP_ASSERT((unsigned __int128)la * lb + (unsigned __int128)lc * ld <= ((unsigned __int128)6 << 58) + ((unsigned __int128)1 << 41), "fe_mul2: L(a)*L(b) + L(c)*L(d) > 6"); }
+#endif
+    u32 m[9];
+    Fe t;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (u64)a.l[i] * b.l[k - i]; acc += (u64)c.l[i] * d.l[k - i]; }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (u64)m[i] * P::P29[k - i];
+        m[k] = ((u32)acc * P::NINV29) & M29;
+        acc += (u64)m[k] * P::P29[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) { acc += (u64)a.l[i] * b.l[k - i]; acc += (u64)c.l[i] * d.l[k - i]; }
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (u64)m[i] * P::P29[k - i];
+        t.l[k - 9] = (u32)acc & M29;
+        acc >>= 29;
+    }
+    ARKBP_ASSERT(acc < (1ull << 29), "fe_mul2: result exceeds 2^261");
     t.l[8] = (u32)acc;
     return t;
 }

@@ -191,14 +191,18 @@ __device__ __forceinline__ Fe load_fe_limbs(const u32* __restrict__ p) {
 // Per-proof split tables for k_vfy_batch.  With i = hi * 2^LOB + lo, and the proof's constants folded into the LOW halves so that the
 // batch kernel gets each weighted quantity with ONE product:
 //   alpha * a * s[i]     (s[i]     = allinv * prod_{bit j of i set} u_sq[k-1-j])    = s_lo[lo] * s_hi[hi]    (inner_product_proof.rs:302-311 in closed form)
-//   b * s[N-1-i]         (s[N-1-i] = allinv * prod_{bit j of i clear} u_sq[k-1-j])  = r_lo[lo] * r_hi[hi]
+//   -b * s[N-1-i]        (s[N-1-i] = allinv * prod_{bit j of i clear} u_sq[k-1-j])  = r_lo[lo] * r_hi[hi]   (the sign rides in r_lo: the
+//                                                                                      batch kernel ADDS it inside one fused product pair)
 //   alpha * x * y^-i                                                                 = yx_lo[lo] * y_hi[hi]
 //   alpha * y^-i                                                                     = ya_lo[lo] * y_hi[hi]
 //   z^e  (e = q + 1 <= Q)                                                            = z_lo[e & 255] * z_hi[e >> 8]
 //   alpha * x * z^e  (the constant terms, whose weight alpha*r*x^2 is (r*x) times this)  = zx_lo[e & 255] * z_hi[e >> 8]
 // Layout per proof (entries of VT_W words: the nine limbs of a product, i.e. < 1.04 p): [s_lo | s_hi | r_lo | r_hi | yx_lo | y_hi | ya_lo | z_lo (256) | z_hi (nzhi) | zx_lo (256)],
 // stride vfy_tab_stride() = 3 * (2^LOB + 2^HIB) + 2^LOB + 512 + nzhi.  grid (ceil(max(2^LOB, 2^HIB, 256, nzhi) / 256), P).
-__host__ __device__ inline size_t vfy_tab_stride(u32 nlo, u32 nhi, u32 nzhi) { return (size_t)3 * (nlo + nhi) + nlo + 256 + nzhi + 256; }
+// ... followed by the proof's constants x, alpha, u, r*x in the same limb form (VFY_TAB_CONSTS entries): k_vfy_batch reads them once
+// per (proof, element) and the packed parameter block costs ~25 unpack instructions per read
+static constexpr u32 VFY_TAB_CONSTS = 4;
+__host__ __device__ inline size_t vfy_tab_stride(u32 nlo, u32 nhi, u32 nzhi) { return (size_t)3 * (nlo + nhi) + nlo + 256 + nzhi + 256 + VFY_TAB_CONSTS; }
 template <class C> __global__ void __launch_bounds__(256)
 k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P, u32 k, u32 LOB, u32 nzhi, u32* __restrict__ tables) {
     typedef typename C::Fr F;
@@ -218,10 +222,14 @@ k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P
         store_fe_limbs(Z + (size_t)(256 + nzhi + tIdx) * VT_W, fe_mul<F>(fe_mul<F>(load_fe_dev<F>(cst + 40), load_fe_dev<F>(cst + 8)), zp));
     }
     if (tIdx < nzhi) store_fe_limbs(Z + (size_t)(256 + tIdx) * VT_W, pow_table<F>(ztab, tIdx << 8));
+    if (tIdx < VFY_TAB_CONSTS) {   // x, alpha, u, r*x
+        const u32 src = tIdx == 0 ? 8u : tIdx == 1 ? 40u : tIdx == 2 ? 32u : 56u;
+        store_fe_limbs(Z + (size_t)(256 + nzhi + 256 + tIdx) * VT_W, load_fe_dev<F>(cst + src));
+    }
     if (tIdx < nlo) {
         const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
         const Fe alpha = load_fe_dev<F>(cst + 40);
-        Fe s = fe_mul<F>(allinv, fe_mul<F>(alpha, a)), r = fe_mul<F>(allinv, b);
+        Fe s = fe_mul<F>(allinv, fe_mul<F>(alpha, a)), r = fe_neg<F, 2>(fe_mul<F>(allinv, b));
         for (u32 j = 0; j < LOB; j++) {
             const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - j) * 8);
             if ((tIdx >> j) & 1) s = fe_mul<F>(s, q); else r = fe_mul<F>(r, q);
@@ -245,39 +253,47 @@ k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P
 }
 
 // grid (ceil(N/256), nchunks).  g_part/h_part: [nchunks][N] resident words; d_part: [nchunks * gridDim.x] resident words.
+// Instruction diet (the kernel is VALU-issue-bound: profiles/r02_sq_vfy_batch_after.txt, ~80 % of the SIMD cycles issue): sums are kept
+// LAZY — limb-wise additions, one carry pass / weak reduction per group of terms instead of per term —, the proof's constants come
+// in limb form from the tables, and x*w_L - b*s[N-1-i] is ONE fused product pair (fe_mul2: a single Montgomery reduction).
 template <class C> __global__ void __launch_bounds__(256)
 k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restrict__ perm, const u32* __restrict__ coef_tabs, u32 coef_stride,
             u32 P, u32 per_chunk, u32 n, u32 n1, u32 N, u32 k, u32* __restrict__ g_part,
             u32* __restrict__ h_part, u32* __restrict__ d_part, const u32* __restrict__ tables, u32 LOB, u32 nzhi) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
+    (void)params; (void)perm;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 chunk = blockIdx.y;
     const u32 p0 = chunk * per_chunk, p1 = min(P, p0 + per_chunk);
+    // accumulators over the chunk's proofs: limb-wise sums of L = 1 values, carried and weakly reduced every fourth proof
+    // (a term has V <= 3: four of them on top of a reduced value stay below the weak reduction's V < 32)
     Fe ag = fe_zero<F>(), ah = fe_zero<F>(), ad = fe_zero<F>();
+    u32 pending = 0;
     if (i < N) {
+        const u32 nlo = 1u << LOB, nhi = 1u << (k - LOB), lo = i & (nlo - 1u), hi = i >> LOB;
+        const size_t stride = vfy_tab_stride(nlo, nhi, nzhi) * VT_W;
         for (u32 p = p0; p < p1; p++) {
-            const u32* pb = params + (size_t)perm[p] * VFY_PB_WORDS;
-            const u32* cst = pb + 512;
             // coefficient values: the template's own table, or this proof's (instances of one gadget differ in public constants
             // and in the challenges their randomized constraints carry)
             const u32* coefs = coef_tabs ? coef_tabs + (size_t)p * coef_stride : t.coefs;
-            const Fe x = load_fe_dev<F>(cst + 8), alpha = load_fe_dev<F>(cst + 40);
-            const u32 nlo = 1u << LOB, nhi = 1u << (k - LOB), lo = i & (nlo - 1u), hi = i >> LOB;
-            const u32* T = tables + (size_t)p * vfy_tab_stride(nlo, nhi, nzhi) * VT_W;
+            const u32* T = tables + (size_t)p * stride;
             const u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * VT_W;   // z^e = Z[e & 255] * Z[256 + (e >> 8)]
+            const u32* K = Z + (size_t)(256 + nzhi + 256) * VT_W;        // x, alpha, u, r*x
+            const Fe alpha = load_fe_limbs(K + VT_W);
             // the proof's constants ride in the low halves of the split tables (k_vfy_tables): one product each
             const Fe A = fe_mul<F>(load_fe_limbs(T + (size_t)lo * VT_W), load_fe_limbs(T + (size_t)(nlo + hi) * VT_W));                                  // alpha * a * s[i]
-            const Fe Bv = fe_mul<F>(load_fe_limbs(T + (size_t)(nlo + nhi + lo) * VT_W), load_fe_limbs(T + (size_t)(nlo + nhi + nlo + hi) * VT_W));        // b * s[N-1-i]
+            const Fe nr_lo = load_fe_limbs(T + (size_t)(nlo + nhi + lo) * VT_W), r_hi = load_fe_limbs(T + (size_t)(nlo + nhi + nlo + hi) * VT_W);         // product: -b * s[N-1-i]
             const Fe yhi = load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * VT_W);
             const Fe YA = fe_mul<F>(load_fe_limbs(T + (size_t)(3 * (nlo + nhi) + lo) * VT_W), yhi);                                                    // alpha * y^-i
             Fe g, h, dl = fe_zero<F>();
             if (i < n) {
                 const Fe YX = fe_mul<F>(load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + lo) * VT_W), yhi);                                                // alpha * x * y^-i
                 // columns i of W_L, W_R, W_O in one pass over their entries sorted by constraint index (equal indices reuse the
-                // power); z^(q+1) is one product of two entries of the proof's split table
+                // power); z^(q+1) is one product of two entries of the proof's split table.  The three sums are lazy: a carry pass
+                // and weak reduction after every sixth entry (limbs of <= 7 summed L = 1 terms fit 32 bits).
                 Fe wL = fe_zero<F>(), wR = fe_zero<F>(), wO = fe_zero<F>(), zp = fe_one<F>();
-                u32 cur = 0;   // exponent zp holds (0 = none yet; q + 1 >= 1 always)
+                u32 cur = 0, since = 0;   // exponent zp holds (0 = none yet; q + 1 >= 1 always)
                 for (u32 e = t.m_off[i], e1 = t.m_off[i + 1]; e < e1; e++) {
                     const u32 ent = t.m_ent[e], q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
                     if (q1 != cur) zp = fe_mul<F>(load_fe_limbs(Z + (size_t)(q1 & 255u) * VT_W), load_fe_limbs(Z + (size_t)(256u + (q1 >> 8)) * VT_W));
@@ -285,30 +301,33 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
                     const u32 cid = t.m_c[e];   // bit 31: the coefficient is +1, bit 30: it is -1 (most gadget constraints): no product
                     Fe term;
                     if (cid & 0x80000000u) term = zp;
-                    else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zp));
+                    else if (cid & 0x40000000u) term = fe_neg<F, 2>(zp);
                     else term = fe_mul<F>(zp, load_fe_dev<F>(coefs + (size_t)cid * 8));
-                    if (vec == 0) wL = fe_addr<F>(wL, term); else if (vec == 1) wR = fe_addr<F>(wR, term); else wO = fe_addr<F>(wO, term);
+                    if (vec == 0) wL = fe_add(wL, term); else if (vec == 1) wR = fe_add(wR, term); else wO = fe_add(wO, term);
+                    if (++since == 6) { wL = fe_wred<F>(fe_norm(wL)); wR = fe_wred<F>(fe_norm(wR)); wO = fe_wred<F>(fe_norm(wO)); since = 0; }
                 }
+                wL = fe_norm(wL); wR = fe_norm(wR); wO = fe_norm(wO);   // L = 1, V <= 2 + 6 * 3
                 // alpha * g = alpha*x*y^-i*wR - alpha*a*s[i];  alpha * h = alpha*y^-i * (x*wL + wO - b*s[N-1-i]) - alpha;
                 // alpha*r*x^2 * y^-i*wR*wL = (r*x) * (alpha*x*y^-i*wR) * wL   (verifier.rs:477-500, weighted by the batch's alpha)
                 const Fe Pr = fe_mul<F>(YX, wR);
                 g = fe_sub<F, 2>(Pr, A);
-                Fe tt = fe_addr<F>(fe_mul<F>(x, wL), wO);
-                tt = fe_sub<F, 2>(tt, Bv);
+                const Fe x = load_fe_limbs(K);
+                Fe tt = fe_mul2<F>(x, wL, nr_lo, r_hi);                  // x*wL - b*s[N-1-i]: one reduction for both products
+                tt = fe_norm(fe_add(tt, wO));
                 h = fe_sub<F, 2>(fe_mul<F>(YA, tt), alpha);
                 dl = fe_mul<F>(Pr, wL);
             } else {
                 g = fe_neg<F, 2>(A);
-                h = fe_sub<F, 2>(fe_neg<F, 2>(fe_mul<F>(YA, Bv)), alpha);
+                h = fe_sub<F, 2>(fe_mul<F>(YA, fe_mul<F>(nr_lo, r_hi)), alpha);
             }
             // u_or_1 = 1 for the phase-1 multipliers, u for the randomized-phase ones and on the padding (verifier.rs:486-489)
             if (i >= n1) {
-                const Fe u = load_fe_dev<F>(cst + 32);
+                const Fe u = load_fe_limbs(K + 2 * VT_W);
                 g = fe_mul<F>(g, u);
                 h = fe_mul<F>(h, u);
             }
-            ag = fe_addr<F>(ag, g);
-            ah = fe_addr<F>(ah, h);
+            ag = fe_add(ag, g);
+            ah = fe_add(ah, h);
             // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms;
             // wcp collects alpha * x * (their sum)
             Fe wcp = fe_zero<F>();
@@ -328,9 +347,11 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
                 if (i < n && t.n_const > i) tsum = fe_sub<F, 4>(dl, wcp);
                 else if (i < n) tsum = dl;
                 else tsum = fe_neg<F, 4>(wcp);
-                ad = fe_addr<F>(ad, fe_mul<F>(load_fe_dev<F>(cst + 56), tsum));
+                ad = fe_add(ad, fe_mul<F>(load_fe_limbs(K + 3 * VT_W), tsum));
             }
+            if (++pending == 4) { ag = fe_wred<F>(fe_norm(ag)); ah = fe_wred<F>(fe_norm(ah)); ad = fe_wred<F>(fe_norm(ad)); pending = 0; }
         }
+        ag = fe_wred<F>(fe_norm(ag)); ah = fe_wred<F>(fe_norm(ah)); ad = fe_wred<F>(fe_norm(ad));
         store_fe_dev<F>(g_part + ((size_t)chunk * N + i) * 8, ag);
         store_fe_dev<F>(h_part + ((size_t)chunk * N + i) * 8, ah);
     }
