@@ -18,8 +18,15 @@ namespace arkbp {
 #if defined(__HIPCC__)
 #define ARKBP_QD __device__ __forceinline__
 // value of x in lane (quad base + k), for every lane of the quad; k compile-time
+// The result is pinned to a VGPR of its own (empty asm): LLVM's DPP combine otherwise folds the move into the consuming VALU
+// instruction, and the folded in-place form it produced here — `v_subrev_u32_dpp v60, v60, v63 quad_perm:[1,1,1,1]`, destination =
+// DPP source — delivered every lane its OWN value on gfx950 (tools/ubench_coop_dbg.hip, profiles/r03_ubench_coop_dbg.txt: the last
+// exchange of qjac_add / qjac_madd came out wrong in the even lanes of every quad, with DPP and with ds_bpermute checks alike;
+// plain v_mov_b32_dpp exchanges are right at every level).
 template <int K> __device__ __forceinline__ u32 quad_bcast(u32 x) {
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, K * 0x55, 0xF, 0xF, false);
+    u32 r = (u32)__builtin_amdgcn_update_dpp(0, (int)x, K * 0x55, 0xF, 0xF, false);
+    asm volatile("" : "+v"(r));
+    return r;
 }
 template <int K> __device__ __forceinline__ Fe quad_bcast_fe(const Fe& a) {
     Fe r;

@@ -62,8 +62,8 @@ def valu_entry(products, seconds, note):
 def kernel_entry(name, ms, launches, alg_bytes, traffic, products, note=""):
     """one row of roofline.kernels: everything per UNIT (one proof / one launch, stated in `per`)"""
     sec = ms * 1e-3
-    e = {"kernel": name, "ms": ms, "launches": launches, "algorithmic_bytes": alg_bytes, "hbm_GBps": alg_bytes / sec / 1e9 if sec > 0 else None,
-         "hbm_frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None, "counter_traffic_bytes": traffic,
+    e = {"kernel": name, "ms": ms, "launches": launches, "algorithmic_bytes": alg_bytes, "hbm_GBps": alg_bytes / sec / 1e9 if (alg_bytes and sec > 0) else None,
+         "hbm_frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS if (alg_bytes and sec > 0) else None, "counter_traffic_bytes": traffic,
          "traffic_ratio": (traffic / alg_bytes) if (traffic and alg_bytes) else None, "products": products,
          "valu_instructions": products * VALU_INSTR_PER_PRODUCT if products else None,
          "valu_G_modmul_per_s": products / sec / 1e9 if (products and sec > 0) else None,
