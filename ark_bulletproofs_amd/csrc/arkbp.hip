@@ -134,6 +134,10 @@ struct IpaState {
     bool have_qw = false;      // Q = qw * B (the R1CS prover's Q, prover.rs:779): lets round 1 run as a fixed-base MSM over the tables
     F4 qw;
     int msm_mode = -1;
+    // deferred first fold (ipa.cuh "TWO fold rounds from the tables"): round 1's multipliers are kept, G and H stay the generator
+    // tables for one more round, and the second fold produces Ghat'' / Hhat'' straight from the tables
+    bool deferred = false;
+    F4 def_tG, def_tH;
     F4 geo_k0;                  // index-cyclic slices: the geometric H factor of local element j is K * rho^(rank + j*world) = (K * geo_k0) * (rho^world)^j
     bool have_k0 = false;
 };
@@ -199,6 +203,7 @@ struct bp_ctx {
     size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
     size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
     size_t tune_host_threads = 0;                  // BP_TUNE_HOST_THREADS: size of this ctx's host pool (0 = host_pool_threads())
+    bool msm_latency_first = false;                // set by the bp_msm* entry points for the duration of the call (see msm_use_quad)
     size_t tune_msm_glv_min = 256;                 // BP_TUNE_MSM_GLV_MIN: terms from which an MSM on a GLV curve splits its scalars
     DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
     // fixed-base MSM rows of the generators (bp_gens_msm_tables): row r of a table = 2^(4r) * base, r < FB_ROWS, layout [r][i]
@@ -306,11 +311,17 @@ static MsmPlan msm_plan(size_t n, int bits) {
 
 // quad-cooperative additions in the latency-bound kernels of the fixed-shape pipeline (ecq.cuh); ARKBP_MSM_NOQUAD=1 restores the
 // lane-per-addition kernels (A/B: profiles/r03_msm_quad_ab.txt)
-static bool msm_use_quad() { static const bool on = getenv("ARKBP_MSM_QUAD") != nullptr; return on; }
+// Policy (measured, profiles/r03_msm_quad_glv_ab.txt): the GLV split and the quad-cooperative trees shorten ONE mid-size MSM
+// (2^16 terms: 0.607 -> 0.513 ms wall) but do not lower its arithmetic — the split adds an endomorphism product to every second
+// mixed addition, a quad addition issues 20 products where a lane issues 16 — so a caller that keeps the GPU full with many MSMs in
+// flight (the prover pipeline: eight streams) gains nothing and pays ~5 % on the accumulate.  They are therefore used where the
+// caller waits for the one result: the bp_msm* entry points.  ARKBP_MSM_LATENCY=1 / =0 forces them on / off everywhere (A/B).
+static int msm_latency_env() { static const int v = getenv("ARKBP_MSM_LATENCY") ? atoi(getenv("ARKBP_MSM_LATENCY")) : -1; return v; }
+static bool msm_use_quad(const bp_ctx* ctx) { const int e = msm_latency_env(); return e >= 0 ? e != 0 : ctx->msm_latency_first; }
 // (direct launches in both branches: a kernel template named only inside a conditional expression is not emitted for the device)
-#define MSM_LAUNCH_REDUCE_FS(red_g, grid, ...) do { if (msm_use_quad() && (red_g) == 4u) hipLaunchKernelGGL((k_msm_reduce_fs<C, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
+#define MSM_LAUNCH_REDUCE_FS(red_g, grid, ...) do { if (msm_use_quad(ctx) && (red_g) == 4u) hipLaunchKernelGGL((k_msm_reduce_fs<C, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
                                                     else hipLaunchKernelGGL((k_msm_reduce_fs<C, false>), grid, dim3(256), 0, st, __VA_ARGS__); } while (0)
-#define MSM_LAUNCH_MARGINALS_FS(grid, ...) do { if (msm_use_quad()) hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
+#define MSM_LAUNCH_MARGINALS_FS(grid, ...) do { if (msm_use_quad(ctx)) hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
                                                 else hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, false>), grid, dim3(256), 0, st, __VA_ARGS__); } while (0)
 // ---- the fixed-shape pipeline over GLV-split scalars (msm.cuh "GLV split"): 2n half-terms of 128 bits ------------------------------
 // Same five launches as the fixed-shape pipeline in msm_run; what changes is the plan — half the windows, hence half the buckets
@@ -487,7 +498,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if constexpr (C::HAS_GLV) {
         // mid-size MSMs on a curve with the endomorphism: the fixed-shape pipeline over GLV-split scalars (half the windows)
         static const bool no_glv = getenv("ARKBP_MSM_NOGLV") != nullptr, no_fs0 = getenv("ARKBP_MSM_NOFS") != nullptr;
-        if (!no_glv && !no_fs0 && !sharded && w_hi < 0 && ctx->shard_world == 1 && !segs.fixed_c4 && n >= std::max<size_t>(ctx->tune_msm_bin_min, ctx->tune_msm_glv_min) && n < ((size_t)1 << 27)) {
+        if (!no_glv && !no_fs0 && msm_use_quad(ctx) && !sharded && w_hi < 0 && ctx->shard_world == 1 && !segs.fixed_c4 && n >= std::max<size_t>(ctx->tune_msm_bin_min, ctx->tune_msm_glv_min) && n < ((size_t)1 << 27)) {
             bool done = false;
             BPCHK(msm_run_fs_glv<C>(ctx, segs, d_scalars, n, scalars_mont, result, done));
             if (done) return BP_OK;
@@ -945,8 +956,10 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
 }
 
 // MSM over the resident generator tables (no base upload): bases = G[off..off+n) (if use_G) || H[off..off+n) (if use_H) || extras
+struct MsmLatencyScope { bp_ctx* c; bool prev; MsmLatencyScope(bp_ctx* c_) : c(c_), prev(c_->msm_latency_first) { c->msm_latency_first = true; } ~MsmLatencyScope() { c->msm_latency_first = prev; } };
 template <class C> static int msm_gens_entry(bp_ctx* c, int use_G, int use_H, size_t off, size_t n, const uint64_t* extra_xy, size_t n_extra,
                                              const uint64_t* scalars, int canonical, uint64_t out_xy[8]) {
+    MsmLatencyScope latency(c);
     const size_t ng = use_G ? n : 0, nh = use_H ? n : 0, total = ng + nh + n_extra;
     if (total == 0) { memset(out_xy, 0, 64); return BP_OK; }
     BPCHK(c->io_scal.ensure(total * 32));
@@ -988,6 +1001,7 @@ template <class C> static void aff_out(uint64_t out[8], const A4& a) { memcpy(ou
 
 template <class C> static int msm_dev_entry(bp_ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, int canonical, uint64_t out_xy[8],
                                             int w_lo = 0, int w_hi = -1) {
+    MsmLatencyScope latency(ctx);
     BaseSegs segs; memset(&segs, 0, sizeof segs);
     segs.nseg = 1; segs.ptr[0] = (const u32*)d_bases; segs.start[0] = 0; segs.start[1] = (u32)n;
     J4 r;
@@ -1263,6 +1277,38 @@ template <class C> static int launch_tab_fold(bp_ctx* ctx, const IpaState& s, u3
     return BP_OK;
 }
 
+// whether the first fold of a prover round can be deferred (ipa.cuh "TWO fold rounds from the tables"): the vectors are the ctx's
+// generator tables read in place, the fold tables cover the bases [0, n + n/2), both multipliers have table digits, and neither this
+// round nor the next reaches the frozen-tail length
+template <class C> static bool fold_can_defer(bp_ctx* ctx, const IpaState& s, size_t n, const F4& tG1, const F4& tH1) {
+    static const bool off = getenv("ARKBP_FOLD_NODEFER") != nullptr || getenv("ARKBP_FOLD_NOTAB") != nullptr;   // A/B switches
+    if (off || !ctx->ftab_n || !s.d_G_in || !s.d_H_in || s.gens_stride != 1 || s.gens_first != 0 || ctx->shard_world > 1 || s.msm_mode != -1) return false;
+    if (n < 256 || (n & 1) || n + n / 2 > ctx->ftab_n) return false;
+    if (s.allow_freeze && n / 2 <= std::max<size_t>(ctx->tune_ipa_freeze_len, 2)) return false;
+    if (!s.have_rho) return false;
+    FtabDigits d;
+    return ftab_digits<C>(ctx, tG1, d) && ftab_digits<C>(ctx, tH1, d);
+}
+// the second fold after a deferred first one, straight from the tables: m outputs per vector; false when a multiplier has no digits
+template <class C> static int launch_tab_fold2(bp_ctx* ctx, const IpaState& s, u32* d_G, u32* d_H, size_t m, const F4& t2G, const F4& t2H, bool& done) {
+    typedef host::Fld<typename C::Fr> S;
+    done = false;
+    FtabDigits3 dG, dH;
+    if (!ftab_digits<C>(ctx, s.def_tG, dG.d1) || !ftab_digits<C>(ctx, t2G, dG.d2) || !ftab_digits<C>(ctx, S::mul(s.def_tG, t2G), dG.d12)) return BP_OK;
+    if (!ftab_digits<C>(ctx, s.def_tH, dH.d1) || !ftab_digits<C>(ctx, t2H, dH.d2) || !ftab_digits<C>(ctx, S::mul(s.def_tH, t2H), dH.d12)) return BP_OK;
+    const u32 lanes = (u32)(2 * m);
+    FoldFinish ff;
+    BPCHK(fold_finish_plan(ctx, lanes, ff));
+    {
+        ScopedK tk(ctx, BP_K_FOLD_TAB);
+        hipLaunchKernelGGL(k_ipa_fold_tab2<C>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, ctx->ftab_G.as<u32>(), ctx->ftab_H.as<u32>(), (u32)ctx->ftab_n,
+                           1u << (ctx->ftab_w - 1), d_G, d_H, (u32)m, dG, dH, ff.jac, s.d_G_in, s.d_H_in);
+    }
+    fold_finish_launch<C>(ctx, ff, d_G, d_H, m, 3, lanes);
+    done = true;
+    return BP_OK;
+}
+
 // State of one InnerProductProof::create in flight (the loop body of src/inner_product_proof.rs:70-237 cut at the Fiat-Shamir
 // step): ipa_round_lr computes L, R of the current round, ipa_round_fold consumes the challenge.  ipa_create_dev drives it with a
 // callback; bp_ipa_begin / bp_ipa_round_LR / bp_ipa_round_fold / bp_ipa_finish expose the same steps for hosts that keep the
@@ -1310,6 +1356,44 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
         J4 Lj, Rj;
         BPCHK(msm_run<C>(ctx, sg, sL, 2 * n0 + 1, 0, Lj, 0, -1, s.msm_mode));
         BPCHK(msm_run<C>(ctx, sg, sR, 2 * n0 + 1, 0, Rj, 0, -1, s.msm_mode));
+        A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
+        memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
+        memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
+        s.lr_done = true;
+        return BP_OK;
+    }
+    if (s.deferred) {
+        // the round after a deferred first fold: L and R over the generator tables themselves with split scalars (4n + 1 terms each)
+        const size_t n1 = s.n;   // half length of round 1 = current length of a, b
+        {
+            ScopedK tk(ctx, BP_K_IPA_SCALARS);
+            hipLaunchKernelGGL(k_ipa_scalars_deferred<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, (u32)n, sL, sR, ctx->ipa_part.as<u32>(), s.pending ? (s.h_geo ? 2 : 1) : 0,
+                               words_of<S>(s.gamma_G), words_of<S>(s.gamma_H), s.d_rho_pow, words_of<S>(s.def_tG), words_of<S>(s.def_tH));
+            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 4 * n * 8, sR + 4 * n * 8, words_of<S>(s.qw), s.have_qw ? 1 : 0);
+        }
+        const size_t gofs = (size_t)(s.d_G_in - ctx->d_G.as<u32>()) / 16, hofs = (size_t)(s.d_H_in - ctx->d_H.as<u32>()) / 16;
+        J4 Lj, Rj; bool dl = false, dr = false;
+        if (s.have_qw && s.msm_mode == -1) {
+            ScalSegs ss; memset(&ss, 0, sizeof ss);
+            ss.nseg = 2; ss.ptr[0] = sL; ss.start[0] = 0; ss.start[1] = (u32)(4 * n); ss.ptr[1] = sL + (4 * n + 1) * 8; ss.start[2] = (u32)(4 * n + 1);
+            FbRun rl[5] = {{0, gofs + n1 + n, n}, {0, gofs + n, n}, {1, hofs + n1, n}, {1, hofs, n}, {2, 0, 1}};
+            BPCHK(msm_fixed_run<C>(ctx, rl, 5, ss, 4 * n + 1, 0, Lj, dl));
+            if (dl) {
+                ss.ptr[0] = sR; ss.ptr[1] = sR + (4 * n + 1) * 8;
+                FbRun rr[5] = {{0, gofs + n1, n}, {0, gofs, n}, {1, hofs + n1 + n, n}, {1, hofs + n, n}, {2, 0, 1}};
+                BPCHK(msm_fixed_run<C>(ctx, rr, 5, ss, 4 * n + 1, 0, Rj, dr));
+            }
+        }
+        if (!(dl && dr)) {
+            BaseSegs sg; memset(&sg, 0, sizeof sg);
+            sg.nseg = 5;
+            for (int k = 0; k <= 4; k++) sg.start[k] = (u32)(k * n);
+            sg.start[5] = (u32)(4 * n + 1);
+            sg.ptr[0] = s.d_G_in + (n1 + n) * 16; sg.ptr[1] = s.d_G_in + n * 16; sg.ptr[2] = s.d_H_in + n1 * 16; sg.ptr[3] = s.d_H_in; sg.ptr[4] = s.d_Q;
+            BPCHK(msm_run<C>(ctx, sg, sL, 4 * n + 1, 0, Lj, 0, -1, s.msm_mode));
+            sg.ptr[0] = s.d_G_in + n1 * 16; sg.ptr[1] = s.d_G_in; sg.ptr[2] = s.d_H_in + (n1 + n) * 16; sg.ptr[3] = s.d_H_in + n * 16;
+            BPCHK(msm_run<C>(ctx, sg, sR, 4 * n + 1, 0, Rj, 0, -1, s.msm_mode));
+        }
         A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
         memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
         memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
@@ -1400,6 +1484,12 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
             const F4 ginv = S::inv(s.gf_halves[1]);
             const F4 tG1 = S::mul(S::mul(ui, s.gf_halves[0]), S::inv(s2)), tH1 = S::mul(S::mul(S::sqr(u), S::mul(s.gf_halves[0], ginv)), s.rho_pw[k]);
             bool tab_done = false;
+            if (fold_can_defer<C>(ctx, s, n, tG1, tH1)) {
+                // TWO rounds from the tables: nothing is materialised now; the next round's L / R run over the tables with split scalars
+                // and its fold (below, `s.deferred`) computes Ghat'' / Hhat'' directly
+                s.deferred = true; s.def_tG = tG1; s.def_tH = tH1;
+                tab_done = true;
+            } else
             BPCHK(launch_tab_fold<C>(ctx, s, d_G, d_H, n, tG1, tH1, tab_done));   // the bases are the generator tables themselves: fixed-base look-ups
             if (!tab_done) { BPCHK(working_copy()); BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, tG1, tH1, 3)); }
             s.gamma_G = S::mul(s.gamma_G, s2);
@@ -1429,6 +1519,22 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
             // Ghat' = G_R + u^-2 * G_L, gamma_G *= u;   Hhat' = H_R + u^2 * H_L, gamma_H *= u^-1
             // (geometric pending factor: c[i]/c[n+i] = rho^-n joins t, and K picks up rho^n)
             const int k = ipa_lg2(n);
+            const F4 t2G = S::sqr(ui), t2H = s.h_geo ? S::mul(S::sqr(u), s.rho_pw[k]) : S::sqr(u);
+            if (s.deferred) {
+                bool done2 = false;
+                BPCHK(launch_tab_fold2<C>(ctx, s, d_G, d_H, n, t2G, t2H, done2));
+                if (!done2) {   // (a multiplier whose digits do not fit: materialise round 1 after all, then the ladder)
+                    bool done1 = false;
+                    BPCHK(launch_tab_fold<C>(ctx, s, d_G, d_H, 2 * n, s.def_tG, s.def_tH, done1));
+                    if (!done1) {
+                        HIPCHK(hipMemcpyAsync(d_G, s.d_G_in, 4 * n * 64, hipMemcpyDeviceToDevice, st));
+                        HIPCHK(hipMemcpyAsync(d_H, s.d_H_in, 4 * n * 64, hipMemcpyDeviceToDevice, st));
+                        BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, 2 * n, s.def_tG, s.def_tH, 3));
+                    }
+                    BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, t2G, t2H, 3));
+                }
+                s.deferred = false;
+            } else
             BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, S::sqr(ui), s.h_geo ? S::mul(S::sqr(u), s.rho_pw[k]) : S::sqr(u), 3));
             s.gamma_G = S::mul(s.gamma_G, u);
             s.gamma_H = s.h_geo ? S::mul(S::mul(s.gamma_H, ui), s.rho_pw[32 + k]) : S::mul(s.gamma_H, ui);
@@ -1437,7 +1543,7 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
     }
     HIPCHK(hipGetLastError());
     s.first = false;
-    s.d_G_in = s.d_H_in = nullptr;
+    if (!s.deferred) s.d_G_in = s.d_H_in = nullptr;   // (a deferred fold keeps reading the generator tables for one more round)
     s.round++;
     s.n = n;
     s.lr_done = false;

@@ -134,6 +134,53 @@ k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* _
         store_fe_dev<F>(partials + (size_t)blockIdx.x * 16 + 8, pr);
     }
 }
+// The MSM scalars of the round AFTER a deferred first fold (see k_ipa_fold_tab2): a and b are folded, G and H are still the
+// generator tables, Ghat'[j] = G[n+j] + tG1 * G[j] and Hhat'[j] = H[n+j] + tH1 * H[j] exist only as formulas.  With half length m
+// (= n/2) and x_l, y_l, x_r, y_r as in k_ipa_scalars (pending factors included):
+//   L = sum x_l[i] * Ghat'[m+i] + sum y_l[i] * Hhat'[i]  = <x_l, G[n+m..)> + <x_l*tG1, G[m..)> + <y_l, H[n..)> + <y_l*tH1, H[0..)>
+//   R = sum x_r[i] * Ghat'[i]   + sum y_r[i] * Hhat'[m+i]= <x_r, G[n..)>   + <x_r*tG1, G[0..)> + <y_r, H[n+m..)> + <y_r*tH1, H[m..)>
+// sL / sR: 4m scalars in that order (canonical integers), then the inner products (k_ipa_ip_finish).
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_scalars_deferred(const u32* __restrict__ a, const u32* __restrict__ b, u32 m, u32* __restrict__ sL, u32* __restrict__ sR, u32* __restrict__ partials,
+                       int pending, Words8 gGw, Words8 gHw, const u32* __restrict__ rho_pow, Words8 tG1w, Words8 tH1w) {
+    typedef typename C::Fr F;
+    __shared__ u32 sh[9 * 256];
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fe pl = fe_zero<F>(), pr = fe_zero<F>();
+    if (i < m) {
+        Fe aL = load_fe_dev<F>(a + (size_t)i * 8), aR = load_fe_dev<F>(a + (size_t)(m + i) * 8);
+        Fe bL = load_fe_dev<F>(b + (size_t)i * 8), bR = load_fe_dev<F>(b + (size_t)(m + i) * 8);
+        pl = fe_mul<F>(aL, bR);
+        pr = fe_mul<F>(aR, bL);
+        Fe xl = aL, yl = bR, xr = aR, yr = bL;
+        if (pending) {
+            const Fe gG = fe_load_ark<F>(gGw.w), gH = fe_load_ark<F>(gHw.w);
+            xl = fe_mul<F>(xl, gG); xr = fe_mul<F>(xr, gG);
+            if (pending == 2) {
+                const Fe ri = fe_mul<F>(gH, pow_table<F>(rho_pow, i));
+                yl = fe_mul<F>(yl, ri);
+                yr = fe_mul<F>(yr, fe_mul<F>(ri, pow_table<F>(rho_pow, m)));
+            } else {
+                yl = fe_mul<F>(yl, gH); yr = fe_mul<F>(yr, gH);
+            }
+        }
+        const Fe tG1 = fe_load_ark<F>(tG1w.w), tH1 = fe_load_ark<F>(tH1w.w);
+        store_fe_canon<F>(sL + (size_t)i * 8, xl);
+        store_fe_canon<F>(sL + (size_t)(m + i) * 8, fe_mul<F>(xl, tG1));
+        store_fe_canon<F>(sL + (size_t)(2 * m + i) * 8, yl);
+        store_fe_canon<F>(sL + (size_t)(3 * m + i) * 8, fe_mul<F>(yl, tH1));
+        store_fe_canon<F>(sR + (size_t)i * 8, xr);
+        store_fe_canon<F>(sR + (size_t)(m + i) * 8, fe_mul<F>(xr, tG1));
+        store_fe_canon<F>(sR + (size_t)(2 * m + i) * 8, yr);
+        store_fe_canon<F>(sR + (size_t)(3 * m + i) * 8, fe_mul<F>(yr, tH1));
+    }
+    pl = block_sum_fe<F>(fe_wred<F>(pl), sh);
+    pr = block_sum_fe<F>(fe_wred<F>(pr), sh);
+    if (threadIdx.x == 0) {
+        store_fe_dev<F>(partials + (size_t)blockIdx.x * 16, pl);
+        store_fe_dev<F>(partials + (size_t)blockIdx.x * 16 + 8, pr);
+    }
+}
 template <class C> __global__ void __launch_bounds__(256)
 k_ipa_ip_finish(const u32* __restrict__ partials, u32 nparts, u32* __restrict__ outL, u32* __restrict__ outR, Words8 qw, int with_qw) {
     typedef typename C::Fr F;
@@ -570,6 +617,54 @@ k_ipa_fold_tab(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_tab
     const u32* Vin = isH ? (Hin ? Hin : H) : (Gin ? Gin : G);
     acc = jac_madd<C>(acc, load_aff_dev(Vin + (size_t)(n + i) * 16));
     fold_emit<C>(V, i, t, acc, jac_ws);
+}
+
+// ---- TWO fold rounds from the tables ------------------------------------------------------------------------------------------
+// The first fold round need not be materialised at all: with the second round's multiplier t2 known,
+//   Ghat''[i] = Ghat'[m+i] + t2 * Ghat'[i] = G[n+m+i] + t1 * G[m+i] + t2 * G[n+i] + (t1*t2) * G[i]        (n = 2m; same for H)
+// is three fixed-base multiplications of GENERATORS — table look-ups, no doublings — instead of one table round (n points) plus
+// one ladder round (m points, 130 doublings + ~88 mixed adds each).  The second round's L and R are MSMs over the generator tables
+// with split scalars (k_ipa_scalars_deferred), i.e. fixed-base MSMs over the precomputed rows.  Needs tables for bases [0, n+m).
+// d1 / d2 / d12: digits of t1, t2, t1*t2 (per vector).
+struct FtabDigits3 {
+    FtabDigits d1, d2, d12;
+};
+template <class C> __device__ __forceinline__ Jac ftab_mul_acc(Jac acc, const u32* __restrict__ T, u32 n_tab, u32 E, u32 gi, const FtabDigits& d) {
+    typedef typename C::Fq F;
+#pragma unroll 1
+    for (u32 j = 0; j < d.nwin; j++) {
+        const u32 e1 = d.e1[j], e2 = d.e2[j];
+        if (e1) {
+            const Aff P = load_aff_dev(T + (((size_t)j * E + (e1 - 1)) * n_tab + gi) * 16);
+            acc = jac_madd<C>(acc, aff_cneg_lazy<C>(P, ((d.neg1 >> j) & 1ull) != 0));
+        }
+        if constexpr (C::HAS_GLV) {
+            if (e2) {
+                Aff Q = load_aff_dev(T + (((size_t)j * E + (e2 - 1)) * n_tab + gi) * 16);
+                if (!aff_is_inf(Q)) Q.x = fe_canon<F>(fe_mul<F>(Q.x, fe_const<F, C::BETA29>()));   // phi(x, y) = (beta * x, y)
+                acc = jac_madd<C>(acc, aff_cneg_lazy<C>(Q, ((d.neg2 >> j) & 1ull) != 0));
+            }
+        } else { (void)e2; }
+    }
+    return acc;
+}
+// lanes [0, m): G, lanes [m, 2m): H.  Gin / Hin: the resident generator tables (bases n+m+i are read from them); G / H: the working
+// vectors that receive the m folded points each (or the Jacobian workspace, see fold_emit).
+template <class C> __global__ void __launch_bounds__(256)
+k_ipa_fold_tab2(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_tab, u32 E, u32* __restrict__ G, u32* __restrict__ H, u32 m, FtabDigits3 dG,
+                FtabDigits3 dH, u32* __restrict__ jac_ws, const u32* __restrict__ Gin, const u32* __restrict__ Hin) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * m) return;
+    const bool isH = t >= m;                        // waves are homogeneous for m >= 64
+    const u32 i = isH ? t - m : t;
+    const u32 n = 2 * m;
+    const u32* T = isH ? TH : TG;
+    Jac acc = jac_inf<C>();
+    acc = ftab_mul_acc<C>(acc, T, n_tab, E, m + i, isH ? dH.d1 : dG.d1);     // t1 * Base[m+i]
+    acc = ftab_mul_acc<C>(acc, T, n_tab, E, n + i, isH ? dH.d2 : dG.d2);     // t2 * Base[n+i]
+    acc = ftab_mul_acc<C>(acc, T, n_tab, E, i, isH ? dH.d12 : dG.d12);       // t1*t2 * Base[i]
+    acc = jac_madd<C>(acc, load_aff_dev((isH ? Hin : Gin) + (size_t)(n + m + i) * 16));
+    fold_emit<C>(isH ? H : G, i, t, acc, jac_ws);
 }
 
 }  // namespace arkbp

@@ -33,9 +33,9 @@ static constexpr int MSM_CHL = MSM_CH == 8 ? 3 : MSM_CH == 16 ? 4 : MSM_CH == 32
 static_assert((1 << MSM_CHL) == MSM_CH, "ARKBP_MSM_CH must be 8, 16, 32 or 64");
 static constexpr int MSM_CHL_BINNED = MSM_CHL;   // measured: whole-bucket lanes (64) lose more to divergence and a thin grid than the tree levels cost
 static constexpr int MSM_MAXLVL = 8;   // 16^8 = 2^32 >= any bucket population
-static constexpr int MSM_MAXSEG = 4;
+static constexpr int MSM_MAXSEG = 6;   // (the deferred second IPA round reads G and H in two pieces each, plus B)
 
-// A logical base vector made of up to 4 device-resident segments (e.g. G_R || H_L || Q) — the
+// A logical base vector made of up to MSM_MAXSEG device-resident segments (e.g. G_R || H_L || Q) — the
 // reference materialises such concatenations into fresh Vecs (src/inner_product_proof.rs:86-91).
 struct BaseSegs {
     const u32* ptr[MSM_MAXSEG];   // 16 words per point, packed R' form (aff_store_dev)
@@ -59,7 +59,7 @@ __device__ __forceinline__ const u32* seg_base_ptr(const BaseSegs& s, u32 idx) {
     return s.ptr[k] + (size_t)(idx - s.start[k]) * 16 + (size_t)(w * s.fixed_c4) * s.row_words[k];
 }
 
-// The scalar vector of an MSM, likewise: up to 4 device-resident runs (e.g. blinding || a_L || a_R of a commitment,
+// The scalar vector of an MSM, likewise: up to MSM_MAXSEG device-resident runs (e.g. blinding || a_L || a_R of a commitment,
 // src/r1cs/prover.rs:516-531) read in place instead of being concatenated first.
 struct ScalSegs {
     const u32* ptr[MSM_MAXSEG];   // 8 words per scalar

@@ -214,10 +214,12 @@ def pmc_traffic(keys, applicable, fname, field="largest"):
     try:
         f3 = os.path.join(ROOT, "profiles", fname.replace("r02_", "r03_"))
         d = json.load(open(f3 if os.path.exists(f3) else os.path.join(ROOT, "profiles", fname)))
-        tot = 0.0
+        tot, found = 0.0, 0
         for k in ([keys] if isinstance(keys, str) else keys):
-            tot += (2.0 * d[k]["fetch_KiB_" + field] + d[k]["write_KiB_" + field]) * 1024.0
-        return tot
+            if k in d:      # (a kernel the profiled configuration did not launch contributes nothing)
+                tot += (2.0 * d[k]["fetch_KiB_" + field] + d[k]["write_KiB_" + field]) * 1024.0
+                found += 1
+        return tot if found else None
     except Exception:
         return None
 
@@ -451,8 +453,10 @@ def run_prove(args, rank, world, local):
 
         free_b, _ = torch.cuda.mem_get_info(local)
         budget = int(free_b) - (2 * 65 * 64 * N if args.msm_tables else 0) - P * 3000 * N - (8 << 30)
-        wbits, nbytes = engs[0].gens_fold_tables(N // 2, window_bits=args.fold_table_bits, budget_bytes=max(budget, 1 << 30))
-        tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0}
+        # bases [0, 3N/4): the first TWO fold rounds come straight from the tables (bases [0, N/2) would serve the first round only)
+        tab_count = N * 3 // 4 if (args.fold_tables >= 2 and not window_sharded) else N // 2
+        wbits, nbytes = engs[0].gens_fold_tables(tab_count, window_bits=args.fold_table_bits, budget_bytes=max(budget, 1 << 30))
+        tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0, "bases": tab_count, "rounds_from_tables": 2 if tab_count > N // 2 else 1}
     msm_tab_info = None
     if args.msm_tables and not window_sharded:
         # fixed-base rows of the generators for the MSMs over the tables themselves (commitments, first-round L / R)
@@ -573,11 +577,17 @@ def run_prove(args, rank, world, local):
             # mixed add (11) — with the GLV halves 2 * nwin adds + nwin endomorphism products —, the final add; conversions
             wb = tab_info["window_bits"]
             nwin = (130 if args.curve == 0 else 256) // wb + 1
-            per_lane_tab = (2 * nwin * 11 + nwin if args.curve == 0 else nwin * 11) + 11
-            prod_tab, prod_lad = N * per_lane_tab, (N - 2.0) * (per_lane - 20)
+            per_mult = 2 * nwin * 11 + nwin if args.curve == 0 else nwin * 11        # one fixed-base multiplication: look-ups + mixed adds (+ endomorphism products)
+            if tab_info.get("rounds_from_tables") == 2:
+                # rounds 1 and 2 in one table kernel: N/2 output points, three fixed-base multiplications + the final add each; the ladders
+                # start at round 3 (N/2 - 2 output points)
+                prod_tab, prod_lad = (N / 2.0) * (3 * per_mult + 11), (N / 2.0 - 2.0) * (per_lane - 20)
+            else:
+                prod_tab, prod_lad = N * (per_mult + 11), (N - 2.0) * (per_lane - 20)
         else:
             prod_tab, prod_lad = 0.0, 2.0 * (N - 1) * (per_lane - 20)
-        prod_fin = 2.0 * (N - 1) * 20           # shared inversion (450 / 8 per point) + 3 products to (X/Z^2, Y/Z^3) + canonical forms
+        n_out = (N - 2.0) if (tab_info and tab_info.get("rounds_from_tables") == 2) else 2.0 * (N - 1)      # points that are materialised
+        prod_fin = n_out * 20                   # shared inversion (450 / 8 per point) + 3 products to (X/Z^2, Y/Z^3) + canonical forms
         modmul = prod_tab + prod_lad + prod_fin
         secq20 = args.logn == 20 and args.curve == 0 and bool(args.fold_tables)
         pf = "r02_pmc_prove2p20_summary.json"
@@ -590,9 +600,11 @@ def run_prove(args, rank, world, local):
         cW = E.msm_window_count(args.curve, max(N, 64))
         madds_per_term = (255 if args.curve else 256) // cW[1]       # ordinary schedule; the fixed-base schedule needs fewer (c = 20)
         kernels = [
-            kernel_entry("k_ipa_fold_tab (round 1: fixed-base table look-ups)", tab_ms, tab_n, 576.0 * (N // 2), tr("prove2p20/k_ipa_fold_tab<Secq>"), prod_tab,
+            kernel_entry("k_ipa_fold_tab | k_ipa_fold_tab2 (rounds 1-2: fixed-base table look-ups)", tab_ms, tab_n, 576.0 * (N // 2) * (1.5 if (tab_info and tab_info.get("rounds_from_tables") == 2) else 1.0),
+                         tr(["prove2p20/k_ipa_fold_tab<Secq>", "prove2p20/k_ipa_fold_tab2<Secq>"]), prod_tab,
                          "traffic includes the table rows it streams (34 rows x 64 B per point at w = 8): deliberate, 0.3 ms at HBM speed for ~12 ms of ladder saved"),
-            kernel_entry("k_ipa_fold_glv | k_ipa_fold_uniform (rounds >= 2: scalar-multiplication ladders)", lad_ms, lad_n, 576.0 * (N // 2 - 1),
+            kernel_entry("k_ipa_fold_glv | k_ipa_fold_uniform (the later rounds: scalar-multiplication ladders)", lad_ms, lad_n,
+                         576.0 * ((N // 4 - 1) if (tab_info and tab_info.get("rounds_from_tables") == 2) else (N // 2 - 1)),
                          tr("prove2p20/k_ipa_fold_glv<Secq>"), prod_lad, "a round below 2^16 lanes takes ~1.15 ms whatever its size: one lane's serial ladder"),
             kernel_entry("k_ipa_fold_finish (Jacobian -> affine, one inversion per 8 points)", fin_ms, fin_n, 2.0 * (N - 1) * (96 + 64), tr("prove2p20/k_ipa_fold_finish<Secq>"), prod_fin,
                          "re-reads the Jacobian results the ladders wrote (unfused: 0.58 GB per proof, 0.07 ms at HBM speed)"),
@@ -940,7 +952,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--window", type=int, default=64, help="statements alive at once in the prove pipeline (built, waiting for or in the TranscriptRng stage, "
                     "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s")
-    ap.add_argument("--fold-tables", type=int, default=1, help="prove workload: fixed-base tables of the generators for the first fold round (0 = off)")
+    ap.add_argument("--fold-tables", type=int, default=2, help="prove workload: fixed-base tables of the generators for the first fold rounds (0 = off, 1 = the first round, "
+                    "2 = the first two rounds: tables over 3N/4 bases)")
     ap.add_argument("--msm-tables", type=int, default=1, help="prove workload: fixed-base rows of the generators for the MSMs over the tables themselves (0 = off)")
     ap.add_argument("--sweep-one-curve", action="store_true", help="shuffle-sweep workload: only --curve (default: secq256k1 and zorro)")
     ap.add_argument("--cfg5-logn", type=int, default=22, help="headline with --gpus N > 1: size of the window-sharded proofs of the cfg5 leg (0 = skip the leg)")

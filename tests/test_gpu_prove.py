@@ -304,3 +304,44 @@ def test_prove_with_fixed_base_msm_tables(oracle, fold_tables):
             assert got.proof == ref.proof, (cv, sc, prm)
         e.gens_msm_tables(0)
         e.close()
+
+
+@pytest.mark.parametrize("w", [0, 4])
+def test_prove_two_fold_rounds_from_the_tables(oracle, w):
+    """Fold tables that cover the bases [0, 3N/4): the prover defers its first fold and produces the second round's vectors
+    straight from the tables (k_ipa_fold_tab2), with that round's L / R as MSMs over the generator tables with split scalars
+    (k_ipa_scalars_deferred; fixed-base rows or the ordinary schedule).  Proof bytes must equal the oracle's for single-phase
+    (square chain: constant G factors, geometric H factors), two-phase (shuffle: all factors u) and multi-range circuits, with
+    and without the fixed-base MSM rows, the shared-inversion epilogue on and off; a statement larger than the tables' reach
+    falls back to the single-round table fold."""
+    import ark_bulletproofs_amd as A
+
+    for cv in (0, 1):
+        e = A.Engine(curve=cv)
+        try:
+            N = 4096
+            e.gens_derive(N)
+            wb, nbytes = e.gens_fold_tables(N * 3 // 4, window_bits=w)
+            assert nbytes > 0 and (w == 0 or wb == w)
+            e.set_tuning(2, 16)        # BP_TUNE_IPA_FREEZE_LEN: the frozen tail starts at 16 so that small statements defer their first fold
+            assert e.gens_tables_check()[0] == 0
+            cases = [(3, [4096, 0], 8), (3, [2048, 0], 8), (0, [2049], 4200), (0, [513], 1100), (4, [64, 64, 0], 72), (3, [1024, 0], 8), (3, [1000, 0], 8)]
+            refs = {}
+            for sc, prm, mcap in cases:
+                refs[(sc, tuple(prm))] = oracle.r1cs_prove(cv, sc, prm, SEED, N, m_cap=mcap)
+            for fixed_rows in (False, True):
+                if fixed_rows:
+                    e.gens_msm_tables(N)
+                    e.set_tuning(5, 4096)
+                for batch_min in (65536, 1):
+                    e.set_tuning(0, batch_min)
+                    for sc, prm, mcap in cases:
+                        got = e.prove_scenario(sc, prm, SEED, m_cap=mcap)
+                        assert got.proof == refs[(sc, tuple(prm))].proof, (cv, w, fixed_rows, batch_min, sc, prm)
+                        assert e.verify_scenario(sc, prm, got.proof, got.commitments, got.publics) == 0
+            # tables for only N/2 bases again: the single-round table fold
+            e.gens_fold_tables(N // 2, window_bits=4)
+            sc, prm, mcap = cases[0]
+            assert e.prove_scenario(sc, prm, SEED, m_cap=mcap).proof == refs[(sc, tuple(prm))].proof
+        finally:
+            e.close()
