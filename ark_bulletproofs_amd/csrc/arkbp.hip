@@ -204,6 +204,7 @@ struct bp_ctx {
     size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
     size_t tune_host_threads = 0;                  // BP_TUNE_HOST_THREADS: size of this ctx's host pool (0 = host_pool_threads())
     bool msm_latency_first = false;                // set by the bp_msm* entry points for the duration of the call (see msm_use_quad)
+    size_t tune_fold_quad_max = 0;                 // BP_TUNE_FOLD_QUAD_MAX: fold rounds with at most this many output points run four lanes per point (0 = never)
     size_t tune_msm_glv_min = 256;                 // BP_TUNE_MSM_GLV_MIN: terms from which an MSM on a GLV curve splits its scalars
     DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
     // fixed-base MSM rows of the generators (bp_gens_msm_tables): row r of a table = 2^(4r) * base, r < FB_ROWS, layout [r][i]
@@ -1144,18 +1145,24 @@ template <class C> static int launch_uniform_fold(bp_ctx* ctx, u32* d_G, u32* d_
     FoldFinish ff;
     BPCHK(fold_finish_plan(ctx, lanes, ff));
     bool done = false;
+    // rounds whose points leave most of the chip idle: four lanes per point (ecq.cuh) — ~1.6x less latency per round for 2.5x the
+    // VALU work (profiles/r03_fold_quad_ab.txt); BP_TUNE_FOLD_QUAD_MAX = the largest round (in points) that takes this form
+    const bool quad = lanes >= 64 && lanes <= ctx->tune_fold_quad_max;
+    const u32 grid = quad ? (lanes * 4 + 255) / 256 : (lanes + 255) / 256;
     {
     ScopedK tk(ctx, BP_K_FOLD_LADDER);
     if constexpr (C::HAS_GLV) {
         Naf2 g, h;
         if (glv_pair<C>(tG, tH, g, h)) {
-            hipLaunchKernelGGL(k_ipa_fold_glv<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, g, h, which, ff.jac);
+            if (quad) hipLaunchKernelGGL((k_ipa_fold_glv<C, true>), dim3(grid), dim3(256), 0, st, d_G, d_H, (u32)n, g, h, which, ff.jac);
+            else hipLaunchKernelGGL((k_ipa_fold_glv<C, false>), dim3(grid), dim3(256), 0, st, d_G, d_H, (u32)n, g, h, which, ff.jac);
             done = true;
         }
     }
     if (!done) {
         Naf a = naf_of<S>(tG), b = naf_of<S>(tH);
-        hipLaunchKernelGGL(k_ipa_fold_uniform<C>, dim3((lanes + 255) / 256), dim3(256), 0, st, d_G, d_H, (u32)n, a, b, which, ff.jac);
+        if (quad) hipLaunchKernelGGL((k_ipa_fold_uniform<C, true>), dim3(grid), dim3(256), 0, st, d_G, d_H, (u32)n, a, b, which, ff.jac);
+        else hipLaunchKernelGGL((k_ipa_fold_uniform<C, false>), dim3(grid), dim3(256), 0, st, d_G, d_H, (u32)n, a, b, which, ff.jac);
     }
     }
     fold_finish_launch<C>(ctx, ff, d_G, d_H, n, which, lanes);
@@ -2289,6 +2296,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
         case BP_TUNE_IPA_FREEZE_LEN: c->tune_ipa_freeze_len = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_WSUM_MIN: c->tune_msm_wsum_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_GLV_MIN: c->tune_msm_glv_min = (size_t)value; return BP_OK;
+        case BP_TUNE_FOLD_QUAD_MAX: c->tune_fold_quad_max = (size_t)value; return BP_OK;
     }
     return BP_E_ARG;
 }

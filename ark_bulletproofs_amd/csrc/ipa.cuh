@@ -401,10 +401,13 @@ k_ipa_fold_pts(u32* __restrict__ G, u32* __restrict__ H, const u32* __restrict__
 struct Naf {
     u32 plus[9], minus[9];
 };
-template <class C> __global__ void __launch_bounds__(256)
+// QUAD: four lanes (a DPP quad) share one point's ladder (ecq.cuh) — for the rounds whose points do not fill the chip; lane 0 of
+// the quad emits.
+template <class C, bool QUAD = false> __global__ void __launch_bounds__(256)
 k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf tH, int which /* 1: G only, 2: H only, 3: both */,
                    u32* __restrict__ jac_ws) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 tl = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = QUAD ? tl >> 2 : tl, ql = threadIdx.x & 3u;
     if (t >= (which == 3 ? 2 * n : n)) return;
     const bool isH = which == 2 || (which == 3 && t >= n);  // waves are homogeneous for n >= 64
     const u32 i = (which == 3 && isH) ? t - n : t;
@@ -417,13 +420,13 @@ k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf 
         const u32 ep = isH ? tH.plus[wd] : tG.plus[wd], em = isH ? tH.minus[wd] : tG.minus[wd];
 #pragma unroll 1
         for (int bit = (wd == 8 ? 0 : 31); bit >= 0; bit--) {
-            acc = jac_dbl<C>(acc);
-            if ((ep >> bit) & 1) acc = jac_madd<C>(acc, P1);
-            else if ((em >> bit) & 1) acc = jac_madd<C>(acc, N1);
+            acc = QUAD ? qjac_dbl<C>(acc, ql) : jac_dbl<C>(acc);
+            if ((ep >> bit) & 1) acc = QUAD ? qjac_madd<C>(acc, P1, ql) : jac_madd<C>(acc, P1);
+            else if ((em >> bit) & 1) acc = QUAD ? qjac_madd<C>(acc, N1, ql) : jac_madd<C>(acc, N1);
         }
     }
-    acc = jac_madd<C>(acc, P2);
-    fold_emit<C>(V, i, t, acc, jac_ws);
+    acc = QUAD ? qjac_madd<C>(acc, P2, ql) : jac_madd<C>(acc, P2);
+    if (!QUAD || ql == 0) fold_emit<C>(V, i, t, acc, jac_ws);
 }
 
 // GLV variant of the uniform fold for curves with the j = 0 endomorphism phi(x, y) = (beta*x, y) = [lambda](x, y) (secq256k1):
@@ -432,11 +435,12 @@ k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf 
 struct Naf2 {
     u32 p1[5], m1[5], p2[5], m2[5];   // bit i: digit +1 / -1 at 2^i of t1 (p1/m1) and t2 (p2/m2), 130 digits
 };
-template <class C> __global__ void __launch_bounds__(256)
+template <class C, bool QUAD = false> __global__ void __launch_bounds__(256)
 k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH, int which /* 1: G only, 2: H only, 3: both */,
                u32* __restrict__ jac_ws) {
     typedef typename C::Fq F;
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 tl = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = QUAD ? tl >> 2 : tl, ql = threadIdx.x & 3u;
     if (t >= (which == 3 ? 2 * n : n)) return;
     const bool isH = which == 2 || (which == 3 && t >= n);
     const u32 i = (which == 3 && isH) ? t - n : t;
@@ -453,13 +457,13 @@ k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH
         const u32 c = isH ? tH.p2[wd] : tG.p2[wd], d = isH ? tH.m2[wd] : tG.m2[wd];
 #pragma unroll 1
         for (int bit = (wd == 4 ? 1 : 31); bit >= 0; bit--) {
-            acc = jac_dbl<C>(acc);
-            if (((a | b) >> bit) & 1) { Aff T1 = P1; T1.y = ((b >> bit) & 1) ? N1.y : P1.y; acc = jac_madd<C>(acc, T1); }   // masks are wave-uniform
-            if (((c | d) >> bit) & 1) { Aff T2 = Q1; T2.y = ((d >> bit) & 1) ? N1.y : P1.y; acc = jac_madd<C>(acc, T2); }
+            acc = QUAD ? qjac_dbl<C>(acc, ql) : jac_dbl<C>(acc);
+            if (((a | b) >> bit) & 1) { Aff T1 = P1; T1.y = ((b >> bit) & 1) ? N1.y : P1.y; acc = QUAD ? qjac_madd<C>(acc, T1, ql) : jac_madd<C>(acc, T1); }   // masks are wave-uniform
+            if (((c | d) >> bit) & 1) { Aff T2 = Q1; T2.y = ((d >> bit) & 1) ? N1.y : P1.y; acc = QUAD ? qjac_madd<C>(acc, T2, ql) : jac_madd<C>(acc, T2); }
         }
     }
-    acc = jac_madd<C>(acc, P2);
-    fold_emit<C>(V, i, t, acc, jac_ws);
+    acc = QUAD ? qjac_madd<C>(acc, P2, ql) : jac_madd<C>(acc, P2);
+    if (!QUAD || ql == 0) fold_emit<C>(V, i, t, acc, jac_ws);
 }
 
 // ---- fixed-base tables for the FIRST fold round ------------------------------------------------------------------------------

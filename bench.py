@@ -443,6 +443,12 @@ def run_prove(args, rank, world, local):
     t0 = time.perf_counter()
     engs[0].gens_derive(N)
     t_gens = time.perf_counter() - t0
+    msm_tab_info = None
+    if args.msm_tables and not window_sharded:
+        # fixed-base rows of the generators for the MSMs over the tables themselves (commitments, first-round L / R)
+        t0 = time.perf_counter()
+        nbytes = engs[0].gens_msm_tables(N)
+        msm_tab_info = {"GB": nbytes / 1e9, "build_s": time.perf_counter() - t0}
     tab_info = None
     if args.fold_tables:
         # fixed-base tables of the generators for the first fold round (one-time setup like the derivation above; HBM-resident)
@@ -452,17 +458,11 @@ def run_prove(args, rank, world, local):
         import torch
 
         free_b, _ = torch.cuda.mem_get_info(local)
-        budget = int(free_b) - (2 * 65 * 64 * N if args.msm_tables else 0) - P * 3000 * N - (8 << 30)
+        budget = int(free_b) - P * 3000 * N - (12 << 30)        # (the fixed-base MSM rows are installed already)
         # bases [0, 3N/4): the first TWO fold rounds come straight from the tables (bases [0, N/2) would serve the first round only)
         tab_count = N * 3 // 4 if (args.fold_tables >= 2 and not window_sharded) else N // 2
         wbits, nbytes = engs[0].gens_fold_tables(tab_count, window_bits=args.fold_table_bits, budget_bytes=max(budget, 1 << 30))
         tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0, "bases": tab_count, "rounds_from_tables": 2 if tab_count > N // 2 else 1}
-    msm_tab_info = None
-    if args.msm_tables and not window_sharded:
-        # fixed-base rows of the generators for the MSMs over the tables themselves (commitments, first-round L / R)
-        t0 = time.perf_counter()
-        nbytes = engs[0].gens_msm_tables(N)
-        msm_tab_info = {"GB": nbytes / 1e9, "build_s": time.perf_counter() - t0}
     for e in engs[1:]:
         e.share_gens_from(engs[0])
     if window_sharded:

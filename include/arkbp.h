@@ -406,6 +406,9 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
 #define BP_TUNE_HOST_THREADS 6    /* host threads of this ctx's pool for the per-instance transcript replays of batch verification (0 = default:
                                      the machine's hardware threads, at most 32, or ARKBP_HOST_THREADS); callers that keep several batches in
                                      flight on several ctxs divide the cores among them */
+#define BP_TUNE_FOLD_QUAD_MAX 8    /* fold rounds of the inner-product argument with at most this many output points (G and H together) run with FOUR lanes per
+                                     point (quad-cooperative group arithmetic): shorter rounds, more arithmetic; default 0 = never (a prover that keeps the GPU
+                                     full gains nothing); a latency-bound single prover sets 2^14 */
 #define BP_TUNE_MSM_GLV_MIN 7     /* terms from which a variable-base MSM on secq256k1 splits its scalars with the endomorphism (default 256; a huge value turns it off) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 

@@ -345,3 +345,25 @@ def test_prove_two_fold_rounds_from_the_tables(oracle, w):
             assert e.prove_scenario(sc, prm, SEED, m_cap=mcap).proof == refs[(sc, tuple(prm))].proof
         finally:
             e.close()
+
+
+def test_prove_with_quad_cooperative_fold_rounds(oracle):
+    """BP_TUNE_FOLD_QUAD_MAX: the fold rounds below the threshold run with four lanes per point (ecq.cuh: k_ipa_fold_glv<.., true> on
+    secq256k1, k_ipa_fold_uniform<.., true> on zorro); proofs stay byte-identical to the oracle's, with the frozen tail moved down so
+    that several rounds take the quad form, and with the shared-inversion epilogue forced on and off"""
+    import ark_bulletproofs_amd as A
+
+    for cv in (0, 1):
+        e = A.Engine(curve=cv)
+        try:
+            e.gens_derive(2048)
+            e.set_tuning(8, 1 << 12)     # BP_TUNE_FOLD_QUAD_MAX
+            e.set_tuning(2, 8)           # BP_TUNE_IPA_FREEZE_LEN
+            for batch_min in (65536, 1):
+                e.set_tuning(0, batch_min)
+                for sc, prm, mcap in [(3, [2048, 0], 8), (0, [600], 1300), (1, [64, 12345], 8), (3, [300, 0], 8)]:
+                    ref = oracle.r1cs_prove(cv, sc, prm, SEED, 2048, m_cap=mcap)
+                    got = e.prove_scenario(sc, prm, SEED, m_cap=mcap)
+                    assert got.proof == ref.proof, (cv, batch_min, sc, prm)
+        finally:
+            e.close()
