@@ -87,6 +87,16 @@ struct DevBuf {
         cap = want;
         return BP_OK;
     }
+    // exactly `bytes` (the large precomputed tables: the 25 % growth slack of ensure() would be tens of GB)
+    int ensure_exact(size_t bytes) {
+        if (bytes <= cap) return BP_OK;
+        if (!owned) { g_err = "shared device buffer too small"; return BP_E_ARG; }
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr; cap = 0;
+        HIPCHK(hipMalloc(&p, bytes + 256));
+        cap = bytes + 256;
+        return BP_OK;
+    }
     // buffers whose kernels rely on "all zero between uses" (and restore it themselves): zeroed once, when (re)allocated
     int ensure_zeroed(size_t bytes, hipStream_t st) {
         if (bytes <= cap) return BP_OK;
@@ -804,7 +814,7 @@ template <class C> static int fb_tables_build(bp_ctx* ctx, size_t cap) {
     if (cap == 0 || cap > ctx->gens_cap) { g_err = "msm tables: more bases than installed generators"; return BP_E_GENS_LENGTH; }
     if (!ctx->d_G.owned) { g_err = "msm tables: build them on the ctx that owns the generator tables, then bp_gens_share"; return BP_E_ARG; }
     ctx->fb_cap = 0;
-    BPCHK(ctx->fb_G.ensure((size_t)FB_ROWS * cap * 64)); BPCHK(ctx->fb_H.ensure((size_t)FB_ROWS * cap * 64)); BPCHK(ctx->fb_pc.ensure((size_t)FB_ROWS * 2 * 64));
+    BPCHK(ctx->fb_G.ensure_exact((size_t)FB_ROWS * cap * 64)); BPCHK(ctx->fb_H.ensure_exact((size_t)FB_ROWS * cap * 64)); BPCHK(ctx->fb_pc.ensure((size_t)FB_ROWS * 2 * 64));
     const size_t slab = std::min<size_t>(cap, (size_t)1 << 18);   // bounds the Jacobian scratch: 65 rows x 2^18 x 96 B = 1.6 GB
     DevBuf tmp, pref, outb;
     BPCHK(tmp.ensure(FB_ROWS * slab * 96)); BPCHK(pref.ensure(FB_ROWS * slab * 32)); BPCHK(outb.ensure(FB_ROWS * slab * 64));
@@ -1219,9 +1229,9 @@ template <class C> static int ftab_build(bp_ctx* ctx, size_t n, int w, size_t bu
     const size_t E = (size_t)1 << (w - 1);
     const int nwin = ftab_nwin_for<C>(w);
     const size_t per_vec = (size_t)nwin * E * n * 64;
-    BPCHK(ctx->ftab_G.ensure(per_vec)); BPCHK(ctx->ftab_H.ensure(per_vec));
+    BPCHK(ctx->ftab_G.ensure_exact(per_vec)); BPCHK(ctx->ftab_H.ensure_exact(per_vec));
     DevBuf tmp, pref, state;
-    BPCHK(tmp.ensure(E * n * 96)); BPCHK(pref.ensure(E * n * 32)); BPCHK(state.ensure(n * 96));
+    BPCHK(tmp.ensure_exact(E * n * 96)); BPCHK(pref.ensure_exact(E * n * 32)); BPCHK(state.ensure_exact(n * 96));
     const u32 gb = (u32)((n + 255) / 256);
     for (int v = 0; v < 2; v++) {
         const u32* gens = v ? ctx->d_H.as<u32>() : ctx->d_G.as<u32>();

@@ -244,9 +244,9 @@ def test_zorro_prove_verify_roundtrip_2pow16_and_batch():
 
 
 def test_bench_configuration_2pow20_with_tables_checked():
-    """The configuration bench.py times: N = 2^20 on secq256k1 with the first-round fold tables at the
-    automatically chosen window width (w = 8: 146 GB) and the fixed-base MSM rows (8.7 GB).  (a) every entry of both kinds of
-    table passes the chain-rule check, and a single corrupted entry — anywhere, here deep inside the 146 GB — turns it red;
+    """The configuration bench.py times: N = 2^20 on secq256k1 with the fold tables for the first two rounds
+    at the automatically chosen window width (3N/4 bases, w = 8: 219 GB) and the fixed-base MSM rows (8.7 GB).  (a) every entry of both kinds of
+    table passes the chain-rule check, and a single corrupted entry — anywhere, here deep inside the tables — turns it red;
     (b) prove -> verify -> tamper with the tables in use; (c) the same statement proved with the tables released gives the same
     proof bytes."""
     import ark_bulletproofs_amd as A
@@ -256,9 +256,11 @@ def test_bench_configuration_2pow20_with_tables_checked():
     e = A.Engine(curve=cv)
     try:
         e.gens_derive(N)
-        wbits, nbytes = e.gens_fold_tables(N // 2, window_bits=0)          # automatic width: 3/4 of the free HBM (bench.py: what is free minus the workspaces)
-        assert wbits == 8 and nbytes > 100e9
         assert e.gens_msm_tables(N) > 0
+        # bench.py's table settings: bases [0, 3N/4) (the first TWO fold rounds come from the tables), the widest window that fits
+        # what is free after the MSM rows, one proof's workspaces and 12 GB of slack — w = 8, 219 GB on a 288 GB MI355X
+        wbits, nbytes = e.gens_fold_tables(N * 3 // 4, window_bits=0, budget_bytes=288 * 10**9 - 9 * 10**9 - 3000 * N - (12 << 30) - (8 << 30))
+        assert wbits == 8 and nbytes > 200e9
         assert e.gens_tables_check() == (0, 0)
         # corrupt ONE coordinate word of one entry far inside each table, check, restore, check
         for which, slot in ((0, 0), (1, 0), (2, 1), (3, 1)):
