@@ -334,6 +334,34 @@ static bool msm_use_quad(const bp_ctx* ctx) { const int e = msm_latency_env(); r
                                                     else hipLaunchKernelGGL((k_msm_reduce_fs<C, false>), grid, dim3(256), 0, st, __VA_ARGS__); } while (0)
 #define MSM_LAUNCH_MARGINALS_FS(grid, ...) do { if (msm_use_quad(ctx)) hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
                                                 else hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, false>), grid, dim3(256), 0, st, __VA_ARGS__); } while (0)
+// Entries per level-1 chunk of the fixed-shape pipeline.  Throughput callers keep 16.  For a caller waiting on ONE mid-size MSM the
+// accumulate is a single round of workgroups whose duration is (entries per lane) x (latency of a mixed addition at the fill of
+// the lane's SIMD: 6.7 us alone, ~5.6 us per resident wave from two up — tools/ubench_coop.hip): 2^16 terms at 16 entries per chunk
+// make ~100 K lanes = 1.5 waves per SIMD, i.e. every lane waits for the SIMDs that hold two.  The cap is chosen so that the lanes
+// fill a whole number of waves per SIMD with as few entries per lane as that allows (measured at 2^16 terms, secq256k1, accumulate /
+// wall: cap 11 0.200 / 0.520 ms, 12 0.157 / 0.468, 13 0.169 / 0.479, 14 0.181 / 0.487, 16 0.205 / 0.506: profiles/r03_msm_chunk_cap.txt).
+// binned: entries / buckets of the binned windows (bucket populations ~ Poisson); top: the narrow top window (a few full buckets).
+static u32 fs_chunk_cap(const bp_ctx* ctx, double binned_entries, double binned_buckets, double top_entries, double top_buckets) {
+    static const int cap_env = getenv("ARKBP_MSM_FS_CAP") ? atoi(getenv("ARKBP_MSM_FS_CAP")) : 0;   // experiments
+    if (cap_env >= 8 && cap_env <= 64) return (u32)cap_env;
+    if (!msm_use_quad(ctx) || binned_buckets < 1.0) return 1u << MSM_CHL_BINNED;
+    const double lanes_per_fill = 256.0 * 4 * 64;   // one wave on every SIMD of the chip
+    const double mu = binned_entries / binned_buckets, sd = std::sqrt(std::max(mu, 1e-9));
+    u32 best_cap = 1u << MSM_CHL_BINNED; double best_t = 1e300;
+    for (u32 cap = 8; cap <= 32; cap++) {
+        double e_chunks = 0, e_work = 0, wsum = 0;   // E ceil(X / cap) and E X / ceil(X / cap) for X ~ N(mu, mu)
+        for (int q = -30; q <= 30; q++) {
+            const double z = q / 10.0, x = std::max(1.0, mu + sd * z), w = std::exp(-0.5 * z * z), k = std::ceil(x / cap);
+            e_chunks += w * k; e_work += w * x / k; wsum += w;
+        }
+        const double chunks = binned_buckets * e_chunks / wsum + top_entries / cap + 0.5 * top_buckets;
+        const double fill = std::ceil(chunks / lanes_per_fill - 0.004);
+        if (fill > 4.0) continue;   // throughput-bound anyway: the default
+        const double t = (e_work / wsum) * (fill <= 1.0 ? 6.7 : 5.6 * fill) + 0.02 * (chunks / 1000.0);   // (+ the partials the next kernel has to add)
+        if (t < best_t) { best_t = t; best_cap = cap; }
+    }
+    return best_cap;
+}
 // ---- the fixed-shape pipeline over GLV-split scalars (msm.cuh "GLV split"): 2n half-terms of 128 bits ------------------------------
 // Same five launches as the fixed-shape pipeline in msm_run; what changes is the plan — half the windows, hence half the buckets
 // for the reduction / aggregation trees and half the doublings (and marginal sums) of the host's Horner tail.  *done = false when it
@@ -380,14 +408,14 @@ template <class C> static int msm_run_fs_glv(bp_ctx* ctx, const BaseSegs& segs_i
         sp.base[w] = (u32)nslots; sp.cap[w] = (u32)cap;
         nslots += (size_t)bp.top_nb * cap;
     }
-    const int chl_fs = MSM_CHL_BINNED;
+    const u32 chl_fs = fs_chunk_cap(ctx, (double)ne * bp.wb * (1.0 - std::ldexp(1.0, -pl.c)), (double)bp.wb * pl.NB, bp.wb < (u32)pl.W ? (double)ne : 0.0, (double)bp.top_nb);   // (entries per chunk; any value from 8)
     FsPlan fp; memset(&fp, 0, sizeof fp);
     fp.has_top = bp.wb < (u32)pl.W ? 1u : 0u;
     fp.nbins = bp.wb * bp.NBIN + fp.has_top;
     if (fp.has_top) { u32 t = bp.top_nb; while (t) { fp.top_bits++; t >>= 1; } }
     const size_t nwin = (size_t)pl.W;
     const u32 red_g = (size_t)bp.wb * pl.NB > 49152 ? 1u : 4u;
-    const size_t maxch = ((ne * nwin) >> chl_fs) + std::min<size_t>(ne * nwin, nwin * (size_t)pl.NB) + 64;
+    const size_t maxch = (ne * nwin) / chl_fs + std::min<size_t>(ne * nwin, nwin * (size_t)pl.NB) + 64;
     fp.max_chunks = (u32)maxch;
     fp.top_parts = (u32)std::min<size_t>(MSM_TOP_PARTS_MAX, std::max<size_t>(4, ne >> 15));
     const size_t tc = (size_t)bp.wb * pl.c + (size_t)fp.top_bits * fp.top_parts;
@@ -634,15 +662,14 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     if (binned && use_marginals && !no_fs && (bp.wb == (u32)pl.W || bp.top_nb > 0) && (size_t)bp.wb * bp.NBIN + 1 <= MSM_FS_MAXBINS && !segs.fixed_c4) {
         const auto tfs = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t_f0 = mtrace ? tfs() : 0;
-        static const int chl_fs_env = getenv("ARKBP_MSM_FS_CHL") ? atoi(getenv("ARKBP_MSM_FS_CHL")) : 0;   // experiments
-        const int chl_fs = chl_fs_env >= 2 && chl_fs_env <= 6 ? chl_fs_env : MSM_CHL_BINNED;
+        const u32 chl_fs = fs_chunk_cap(ctx, (double)n * bp.wb * (1.0 - std::ldexp(1.0, -pl.c)), (double)bp.wb * pl.NB, bp.wb < (u32)pl.W ? (double)n : 0.0, (double)bp.top_nb);   // (entries per chunk; any value from 8)
         FsPlan fp; memset(&fp, 0, sizeof fp);
         fp.has_top = bp.wb < (u32)pl.W ? 1u : 0u;
         fp.nbins = bp.wb * bp.NBIN + fp.has_top;
         if (fp.has_top) { u32 t = bp.top_nb; while (t) { fp.top_bits++; t >>= 1; } }
         const size_t nwin = (size_t)(pl.w_hi - pl.w_lo);
         const u32 red_g = (size_t)bp.wb * pl.NB > 49152 ? 1u : 4u;   // lanes per bucket of k_msm_reduce_fs: groups while the lanes fit the chip at once, one lane per bucket beyond
-        const size_t maxch = ((n * nwin) >> chl_fs) + std::min<size_t>(n * nwin, nwin * (size_t)pl.NB) + 64;
+        const size_t maxch = (n * nwin) / chl_fs + std::min<size_t>(n * nwin, nwin * (size_t)pl.NB) + 64;
         fp.max_chunks = (u32)maxch;
         const size_t nslots = make_slots(sp, (int)bp.wb, (size_t)bp.wb * bp.NBIN * bp.cap);
         fp.top_parts = (u32)std::min<size_t>(MSM_TOP_PARTS_MAX, std::max<size_t>(4, n >> 15));

@@ -563,18 +563,22 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
     if (j >= nchunks) return;
     const u32 b = find_bucket(off1, B, j);
     u32 beg, end;
+    // a bucket of cnt entries owns k = ceil(cnt / 2^chl) chunks; they share the entries EVENLY (ceil(cnt / k) each) instead of k - 1
+    // full chunks and a remainder: the lanes of a wave then run nearly the same number of mixed adds (a wave lasts as long as its
+    // longest lane: with ~52 entries per bucket the 16 + 16 + 16 + 4 split left a fifth of the lane-steps idle)
+    const u32 r = j - off1[b], k = off1[b + 1] - off1[b];
+    u32 s0, cnt;
     if (slotted == 2) {  // two-level sort: bucket b starts at boff[b]; its population is off0[b+1] - off0[b]
-        beg = boff[b] + ((j - off1[b]) << chl);
-        end = min(beg + (1u << chl), boff[b] + (off0[b + 1] - off0[b]));
+        s0 = boff[b]; cnt = off0[b + 1] - off0[b];
     } else if (slotted) {  // entries = slot array; the bucket's population is off0[b+1] - off0[b]
         const u32 w = b / NB, v = b - w * NB;
-        const u32 s0 = sp.base[w] + v * sp.cap[w];
-        beg = s0 + ((j - off1[b]) << chl);
-        end = min(beg + (1u << chl), s0 + (off0[b + 1] - off0[b]));
+        s0 = sp.base[w] + v * sp.cap[w]; cnt = off0[b + 1] - off0[b];
     } else {
-        beg = off0[b] + ((j - off1[b]) << chl);
-        end = min(beg + (1u << chl), off0[b + 1]);
+        s0 = off0[b]; cnt = off0[b + 1] - off0[b];
     }
+    const u32 per = k > 1 ? (cnt + k - 1) / k : (1u << chl);
+    beg = s0 + min(r * per, cnt);
+    end = min(beg + per, s0 + cnt);
     Jac acc = jac_inf<C>();
     if (beg < end) {
         // the gather of entry e+1 (entry word, then a 64-byte base somewhere in a table far larger than L2) is issued before the
@@ -844,6 +848,7 @@ k_msm_sum_partials(const u32* __restrict__ T_in, u32 count, u32* __restrict__ T_
 // One D2H copy, one wait, the host Horner tail.  A bucket above 256 entries or a full bin raises the flag: the MSM is then redone by
 // the general path (skew-tolerant).  Results are identical either way (a sum of the same group elements).
 static constexpr u32 MSM_FS_MAXBINS = 4096;
+static constexpr u32 MSM_FS_BUCKET_MAX = 256;   // entries of a binned bucket; with chcap >= 8 at most 32 partials reach k_msm_reduce_fs
 static constexpr u32 MSM_TOP_PARTS_MAX = 32;   // (a bit of the slot window collects ~n/32 partials: 4 .. 32 workgroups share them)
 struct FsPlan {
     u32 nbins;      // wb * NBIN (+ 1 when the slot window exists: the last "bin" is that window)
@@ -872,11 +877,11 @@ __device__ __forceinline__ void fs_block_scan(const u32* __restrict__ src, u32 n
 // grid (NBIN, wb + has_top).  Row wb (bin 0 only) is the slot window: hist -> bcnt / loff / boff, hist restored to zero.
 __global__ void __launch_bounds__(256)
 k_msm_bin_sort_fs(u32* __restrict__ ent, u32* __restrict__ bin_cur, u32* __restrict__ hist, u32* __restrict__ boff, u32* __restrict__ bcnt,
-                  u32* __restrict__ loff, u32* __restrict__ bin_chunks, u32* __restrict__ overflow, MsmPlan pl, BinPlan bp, SlotPlan sp, int chl) {
+                  u32* __restrict__ loff, u32* __restrict__ bin_chunks, u32* __restrict__ overflow, MsmPlan pl, BinPlan bp, SlotPlan sp, u32 chcap) {
     extern __shared__ u32 lds[];
     const u32 w = blockIdx.y, bin = blockIdx.x, tid = threadIdx.x;
     const u32 lane = tid & 63u, wv = tid >> 6;
-    const u32 chm = (1u << chl) - 1u;
+    const u32 chm = chcap - 1u;   // chunks of a bucket: ceil(population / chcap) (chcap: 8 .. 64, any value — the host picks it per MSM)
     if (w >= bp.wb) {
         if (bin) return;
         u32* wsum = lds;   // 4 wave sums
@@ -884,7 +889,7 @@ k_msm_bin_sort_fs(u32* __restrict__ ent, u32* __restrict__ bin_cur, u32* __restr
         const u32 per = (nbt + 255u) / 256u;
         u32 runc = 0;
         const u32 capt = sp.cap[wt];   // (a bucket that outgrew its slots raised the overflow flag; only the stored entries may be read)
-        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) runc += (min(hist[wt * pl.NB + x], capt) + chm) >> chl;
+        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) runc += (min(hist[wt * pl.NB + x], capt) + chm) / chcap;
         u32 incl = runc;
         for (int o = 1; o < 64; o <<= 1) { const u32 t2 = __shfl_up(incl, o); if ((int)lane >= o) incl += t2; }
         if (lane == 63) wsum[wv] = incl;
@@ -898,7 +903,7 @@ k_msm_bin_sort_fs(u32* __restrict__ ent, u32* __restrict__ bin_cur, u32* __restr
             bcnt[b] = cn;
             loff[b] = excl;
             boff[b] = sp.base[wt] + x * sp.cap[wt];
-            excl += (cn + chm) >> chl;
+            excl += (cn + chm) / chcap;
         }
         if (tid == 255) bin_chunks[bp.wb * bp.NBIN] = excl;
         return;
@@ -921,7 +926,7 @@ k_msm_bin_sort_fs(u32* __restrict__ ent, u32* __restrict__ bin_cur, u32* __restr
     __syncthreads();
     const u32 per = (NF + 255u) / 256u;
     u32 run = 0, runc = 0, big = 0;
-    for (u32 x = tid * per; x < min((tid + 1) * per, NF); x++) { const u32 cn = cnt[x]; run += cn; runc += (cn + chm) >> chl; big = max(big, cn); }
+    for (u32 x = tid * per; x < min((tid + 1) * per, NF); x++) { const u32 cn = cnt[x]; run += cn; runc += (cn + chm) / chcap; big = max(big, cn); }
     u32 incl = run, inclc = runc;
     for (int o = 1; o < 64; o <<= 1) {
         const u32 t2 = __shfl_up(incl, o), t3 = __shfl_up(inclc, o);
@@ -939,10 +944,10 @@ k_msm_bin_sort_fs(u32* __restrict__ ent, u32* __restrict__ bin_cur, u32* __restr
         loff[b0 + x] = exclc;
         cnt[x] = excl;
         excl += cn;
-        exclc += (cn + chm) >> chl;
+        exclc += (cn + chm) / chcap;
     }
     if (tid == 255) bin_chunks[w * bp.NBIN + bin] = exclc;
-    if (big > (1u << (2 * chl))) *overflow = 1u;   // more partials than k_msm_reduce_fs takes in one step
+    if (big > MSM_FS_BUCKET_MAX) *overflow = 1u;   // more partials than k_msm_reduce_fs takes in one step
     __syncthreads();
     for (u32 x = tid; x < n; x += 256) {
         const u32 e = buf[x];
@@ -957,7 +962,7 @@ __device__ __forceinline__ void fs_bin_range(u32 x, const MsmPlan& pl, const Bin
 }
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __restrict__ bcnt, const u32* __restrict__ loff, const u32* __restrict__ boff,
-               const u32* __restrict__ bin_chunks, u32* __restrict__ out, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32* __restrict__ info) {
+               const u32* __restrict__ bin_chunks, u32* __restrict__ out, MsmPlan pl, BinPlan bp, FsPlan fp, u32 chcap, u32* __restrict__ info) {
     __shared__ u32 base[MSM_FS_MAXBINS + 1];
     __shared__ u32 ws[4];
     fs_block_scan(bin_chunks, fp.nbins, base, ws);
@@ -974,8 +979,11 @@ k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __rest
     while (h2 - l2 > 1) { const u32 mid = (l2 + h2) >> 1; if (loff[b0 + mid] <= jj) l2 = mid; else h2 = mid; }
     const u32 b = b0 + l2;
     const u32 s0 = boff[b];
-    const u32 beg = s0 + ((jj - loff[b]) << chl);
-    const u32 end = min(beg + (1u << chl), s0 + bcnt[b]);
+    const u32 cnt = bcnt[b], r = jj - loff[b];
+    const u32 k = (cnt + chcap - 1u) / chcap;   // the bucket's chunks share its entries evenly (see k_msm_accum)
+    const u32 per = k > 1 ? (cnt + k - 1) / k : chcap;
+    const u32 beg = s0 + min(r * per, cnt);
+    const u32 end = min(beg + per, s0 + cnt);
     Jac acc = jac_inf<C>();
     if (beg < end) {
         u32 ent = entries[beg];
@@ -998,10 +1006,10 @@ k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __rest
     store_jac_ws<C>(out + (size_t)j * 24, acc);
 }
 // G lanes per bucket of the binned windows (G = 4, or 1 when the buckets alone fill the chip): lane q of the group sums partials
-// q, q + G, .. (<= 2^chl in all), lg G shuffle levels join them -> sums[b] (the identity when the bucket is empty)
+// q, q + G, .. (<= 32 in all), lg G shuffle levels join them -> sums[b] (the identity when the bucket is empty)
 template <class C, bool QUAD = false> __global__ void __launch_bounds__(256)
 k_msm_reduce_fs(const u32* __restrict__ part, const u32* __restrict__ bcnt, const u32* __restrict__ loff, const u32* __restrict__ bin_chunks,
-                u32* __restrict__ sums, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32 G) {
+                u32* __restrict__ sums, MsmPlan pl, BinPlan bp, FsPlan fp, u32 chcap, u32 G) {
     __shared__ u32 base[MSM_FS_MAXBINS + 1];
     __shared__ u32 ws[4];
     fs_block_scan(bin_chunks, fp.nbins, base, ws);
@@ -1011,7 +1019,7 @@ k_msm_reduce_fs(const u32* __restrict__ part, const u32* __restrict__ bcnt, cons
     const u32 b = min(gb, nbk - 1u), q = G == 4 ? g & 3u : 0u;   // (whole groups stay in the shuffles; the surplus groups of the last block store nothing)
     const u32 w = b / (u32)pl.NB, v = b - w * (u32)pl.NB;
     const u32 first = base[w * bp.NBIN + (v >> bp.LB)] + loff[b];
-    u32 nch = min((bcnt[b] + (1u << chl) - 1u) >> chl, 1u << chl);
+    u32 nch = min((bcnt[b] + chcap - 1u) / chcap, MSM_FS_BUCKET_MAX / 8u);
     if (first + nch > fp.max_chunks) nch = 0;
     if (QUAD) {
         // G == 4: the four lanes of a bucket are a DPP quad and SHARE every addition (ecq.cuh): the bucket's <= 16 partials as one
@@ -1058,7 +1066,7 @@ template <class C> __device__ __forceinline__ void store_T_ark(u32* __restrict__
 // the level-1 partials of the buckets whose value has bit k.  T_out[wb * c + k * top_parts + part]; info[2] = overflow flag (then cleared).
 template <class C, u32 NT, bool QUAD = false> __global__ void __launch_bounds__(NT)
 k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, const u32* __restrict__ bcnt, const u32* __restrict__ loff,
-                   u32* __restrict__ T_out, MsmPlan pl, BinPlan bp, FsPlan fp, int chl, u32* __restrict__ info, u32* __restrict__ overflow) {
+                   u32* __restrict__ T_out, MsmPlan pl, BinPlan bp, FsPlan fp, u32 chcap, u32* __restrict__ info, u32* __restrict__ overflow) {
     __shared__ u32 pre[2052];      // slot window: prefix counts of the partials of the buckets with bit k (top_nb <= 2048)
     __shared__ u32 wsum[NT / 64];
     __shared__ u32 tree[NT * 27];
@@ -1078,16 +1086,16 @@ k_msm_marginals_fs(const u32* __restrict__ sums, const u32* __restrict__ part, c
         k = t / fp.top_parts;
         const u32 prt = t - k * fp.top_parts;
         const u32 per = (nbt + NT - 1u) / NT;
-        const u32 chm = (1u << chl) - 1u;
+        const u32 chm = chcap - 1u;
         u32 run = 0;
-        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) run += (((x + 1) >> k) & 1u) ? (bcnt[b0t + x] + chm) >> chl : 0u;
+        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) run += (((x + 1) >> k) & 1u) ? (bcnt[b0t + x] + chm) / chcap : 0u;
         u32 incl = run;
         for (int o = 1; o < 64; o <<= 1) { const u32 t2 = __shfl_up(incl, o); if ((int)lane >= o) incl += t2; }
         if (lane == 63) wsum[wv] = incl;
         __syncthreads();
         u32 excl = incl - run;
         for (u32 q = 0; q < wv; q++) excl += wsum[q];
-        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) { pre[x] = excl; excl += (((x + 1) >> k) & 1u) ? (bcnt[b0t + x] + chm) >> chl : 0u; }
+        for (u32 x = tid * per; x < min((tid + 1) * per, nbt); x++) { pre[x] = excl; excl += (((x + 1) >> k) & 1u) ? (bcnt[b0t + x] + chm) / chcap : 0u; }
         if (tid == NT - 1u) pre[nbt] = excl;
         __syncthreads();
         it = prt * NT + tid; it_end = pre[nbt]; it_step = fp.top_parts * NT;

@@ -190,9 +190,10 @@ __device__ __forceinline__ Fe load_fe_limbs(const u32* __restrict__ p) {
 }
 // Per-proof split tables for k_vfy_batch.  With i = hi * 2^LOB + lo, and the proof's constants folded into the LOW halves so that the
 // batch kernel gets each weighted quantity with ONE product:
-//   alpha * a * s[i]     (s[i]     = allinv * prod_{bit j of i set} u_sq[k-1-j])    = s_lo[lo] * s_hi[hi]    (inner_product_proof.rs:302-311 in closed form)
-//   -b * s[N-1-i]        (s[N-1-i] = allinv * prod_{bit j of i clear} u_sq[k-1-j])  = r_lo[lo] * r_hi[hi]   (the sign rides in r_lo: the
-//                                                                                      batch kernel ADDS it inside one fused product pair)
+//   -alpha * a * s[i]    (s[i]     = allinv * prod_{bit j of i set} u_sq[k-1-j])    = s_lo[lo] * s_hi[hi]    (inner_product_proof.rs:302-311 in closed form)
+//   -alpha * y^-i * b * s[N-1-i]  (s[N-1-i] = allinv * prod_{bit j of i clear} u_sq[k-1-j])  = r_lo[lo] * r_hi[hi]   (y^-i splits the same way,
+//                                            so its halves ride in r_lo / r_hi; the signs ride in the low halves: the batch kernel ADDS
+//                                            both quantities inside fused product pairs)
 //   alpha * x * y^-i                                                                 = yx_lo[lo] * y_hi[hi]
 //   alpha * y^-i                                                                     = ya_lo[lo] * y_hi[hi]
 //   z^e  (e = q + 1 <= Q)                                                            = z_lo[e & 255] * z_hi[e >> 8]
@@ -229,45 +230,65 @@ k_vfy_tables(const u32* __restrict__ params, const u32* __restrict__ perm, u32 P
     if (tIdx < nlo) {
         const Fe allinv = load_fe_dev<F>(cst), x = load_fe_dev<F>(cst + 8), a = load_fe_dev<F>(cst + 16), b = load_fe_dev<F>(cst + 24);
         const Fe alpha = load_fe_dev<F>(cst + 40);
-        Fe s = fe_mul<F>(allinv, fe_mul<F>(alpha, a)), r = fe_neg<F, 2>(fe_mul<F>(allinv, b));
+        const Fe ya = fe_mul<F>(alpha, pow_table<F>(ytab, tIdx));
+        Fe s = fe_neg<F, 2>(fe_mul<F>(allinv, fe_mul<F>(alpha, a))), r = fe_mul<F>(fe_neg<F, 2>(fe_mul<F>(allinv, b)), ya);
         for (u32 j = 0; j < LOB; j++) {
             const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - j) * 8);
             if ((tIdx >> j) & 1) s = fe_mul<F>(s, q); else r = fe_mul<F>(r, q);
         }
-        store_fe_limbs(T + (size_t)tIdx * VT_W, s);
+        store_fe_limbs(T + (size_t)tIdx * VT_W, fe_wred<F>(s));
         store_fe_limbs(T + (size_t)(nlo + nhi + tIdx) * VT_W, r);
-        const Fe ya = fe_mul<F>(alpha, pow_table<F>(ytab, tIdx));
         store_fe_limbs(T + (size_t)(2 * (nlo + nhi) + tIdx) * VT_W, fe_mul<F>(ya, x));
         store_fe_limbs(T + (size_t)(3 * (nlo + nhi) + tIdx) * VT_W, ya);
     }
     if (tIdx < nhi) {
-        Fe s = fe_one<F>(), r = s;
+        const Fe yh = pow_table<F>(ytab, tIdx << LOB);
+        Fe s = fe_one<F>(), r = yh;
         for (u32 j = 0; j < HIB; j++) {
             const Fe q = load_fe_dev<F>(usq + (size_t)(k - 1 - (LOB + j)) * 8);
             if ((tIdx >> j) & 1) s = fe_mul<F>(s, q); else r = fe_mul<F>(r, q);
         }
         store_fe_limbs(T + (size_t)(nlo + tIdx) * VT_W, s);
         store_fe_limbs(T + (size_t)(nlo + nhi + nlo + tIdx) * VT_W, r);
-        store_fe_limbs(T + (size_t)(2 * (nlo + nhi) + nlo + tIdx) * VT_W, pow_table<F>(ytab, tIdx << LOB));
+        store_fe_limbs(T + (size_t)(2 * (nlo + nhi) + nlo + tIdx) * VT_W, yh);
     }
 }
 
 // grid (ceil(N/256), nchunks).  g_part/h_part: [nchunks][N] resident words; d_part: [nchunks * gridDim.x] resident words.
 // Instruction diet (the kernel is VALU-issue-bound: profiles/r02_sq_vfy_batch_after.txt, ~80 % of the SIMD cycles issue): sums are kept
 // LAZY — limb-wise additions, one carry pass / weak reduction per group of terms instead of per term —, the proof's constants come
-// in limb form from the tables, and x*w_L - b*s[N-1-i] is ONE fused product pair (fe_mul2: a single Montgomery reduction).
+// in limb form from the tables, and both alpha*g and alpha*h end in ONE fused product pair (fe_mul2: a single Montgomery reduction):
+//   alpha*g = (alpha*x*y^-i)*w_R + (-alpha*a*s[i]),   alpha*h = M + [(alpha*y^-i)*w_O + (-alpha*y^-i*b*s[N-1-i])] - alpha,
+//   M = (alpha*x*y^-i)*w_L, which the delta term reuses: (r*x) * M * w_R.
+// Latency diet (SQ counters: a fifth of the wave cycles waited on memory, and the waits sit in the dependent chain of the column loop —
+// entry word -> table addresses -> table entries -> product): (i) the lane's column entries are the same for every proof of the
+// chunk, so their first VFY_EMAX (entry, coefficient id) pairs are read ONCE into LDS (and the lane's first constant term into
+// registers); (ii) the column loop is software-pipelined: the table entries (and the coefficient) of entry x + 1 are requested
+// before the products of entry x, the operands of the constant term at the top of the proof.  The kernel then needs ~230 VGPRs = two
+// waves per SIMD, which measured faster than three waves without the prefetches.  Staging the proof's z tables in LDS (34 KB per
+// workgroup and proof, two barriers) was measured too and lost: 1.18 ms against 1.10 (profiles/r03_vfy_batch_ab.txt).
+static constexpr u32 VFY_EMAX = 6;
 template <class C> __global__ void __launch_bounds__(256)
 k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restrict__ perm, const u32* __restrict__ coef_tabs, u32 coef_stride,
             u32 P, u32 per_chunk, u32 n, u32 n1, u32 N, u32 k, u32* __restrict__ g_part,
             u32* __restrict__ h_part, u32* __restrict__ d_part, const u32* __restrict__ tables, u32 LOB, u32 nzhi) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
+    __shared__ u32 es[2 * VFY_EMAX * 256];
     (void)params; (void)perm;
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 tid = threadIdx.x;
+    const u32 i = blockIdx.x * blockDim.x + tid;
     const u32 chunk = blockIdx.y;
     const u32 p0 = chunk * per_chunk, p1 = min(P, p0 + per_chunk);
+    u32 e0 = 0, ne = 0;
+    if (i < n) { e0 = t.m_off[i]; ne = t.m_off[i + 1] - e0; }
+    for (u32 x = 0; x < min(ne, VFY_EMAX); x++) { es[x * 256u + tid] = t.m_ent[e0 + x]; es[(VFY_EMAX + x) * 256u + tid] = t.m_c[e0 + x]; }   // (read back by this lane only)
+    // lanes share the constant terms (e = i, i + N, ..): the first one of this lane
+    const bool has_c0 = i < t.n_const;
+    u32 c0_cid = 0x80000000u, c0_q1 = 1;
+    if (has_c0) { c0_cid = t.const_c[i]; c0_q1 = t.const_q[i] + 1u; }   // (a constant per gate is common: the range-proof gadget has one per bit)
     // accumulators over the chunk's proofs: limb-wise sums of L = 1 values, carried and weakly reduced every fourth proof
-    // (a term has V <= 3: four of them on top of a reduced value stay below the weak reduction's V < 32)
+    // (a term has V <= 6: four of them on top of a reduced value stay below the weak reduction's V < 32)
     Fe ag = fe_zero<F>(), ah = fe_zero<F>(), ad = fe_zero<F>();
     u32 pending = 0;
     if (i < N) {
@@ -280,45 +301,79 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
             const u32* T = tables + (size_t)p * stride;
             const u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * VT_W;   // z^e = Z[e & 255] * Z[256 + (e >> 8)]
             const u32* K = Z + (size_t)(256 + nzhi + 256) * VT_W;        // x, alpha, u, r*x
+            // next column entry in flight: its words, the two table entries of its power of z, its coefficient
+            u32 ent_n = 0, cid_n = 0x80000000u, cw_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            Fe zl_n = fe_zero<F>(), zh_n = fe_zero<F>();
+            auto fetch = [&](u32 x) {
+                ent_n = x < VFY_EMAX ? es[x * 256u + tid] : t.m_ent[e0 + x];
+                cid_n = x < VFY_EMAX ? es[(VFY_EMAX + x) * 256u + tid] : t.m_c[e0 + x];
+                const u32 q = (ent_n & 0x3fffffffu) + 1u;
+                zl_n = load_fe_limbs(Z + (size_t)(q & 255u) * VT_W);
+                zh_n = load_fe_limbs(Z + (size_t)(256u + (q >> 8)) * VT_W);
+                if (!(cid_n & 0xc0000000u)) load_words8(cw_n, coefs + (size_t)cid_n * 8);
+            };
+            if (ne) fetch(0);
+            // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms;
+            // wcp collects alpha * x * (their sum).  Computed first: its table reads share the round trip of the reads below, and
+            // alpha * x * z^(q+1) = zx_lo[e & 255] * z_hi[e >> 8] is one product
+            Fe wcp = fe_zero<F>();
+            if (has_c0) {
+                const Fe zq0 = fe_mul<F>(load_fe_limbs(Z + (size_t)(256u + nzhi + (c0_q1 & 255u)) * VT_W), load_fe_limbs(Z + (size_t)(256u + (c0_q1 >> 8)) * VT_W));
+                if (c0_cid & 0x80000000u) wcp = zq0;
+                else if (c0_cid & 0x40000000u) wcp = fe_wred<F>(fe_neg<F, 2>(zq0));
+                else wcp = fe_mul<F>(zq0, load_fe_dev<F>(coefs + (size_t)c0_cid * 8));
+                for (u32 e = i + N; e < t.n_const; e += N) {   // (more constant terms than lanes: rare)
+                    const u32 cid = t.const_c[e];
+                    const u32 q1 = t.const_q[e] + 1u;
+                    const Fe zq = fe_mul<F>(load_fe_limbs(Z + (size_t)(256u + nzhi + (q1 & 255u)) * VT_W), load_fe_limbs(Z + (size_t)(256u + (q1 >> 8)) * VT_W));
+                    Fe term;
+                    if (cid & 0x80000000u) term = zq;
+                    else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zq));
+                    else term = fe_mul<F>(zq, load_fe_dev<F>(coefs + (size_t)cid * 8));
+                    wcp = fe_addr<F>(wcp, term);
+                }
+            }
             const Fe alpha = load_fe_limbs(K + VT_W);
             // the proof's constants ride in the low halves of the split tables (k_vfy_tables): one product each
-            const Fe A = fe_mul<F>(load_fe_limbs(T + (size_t)lo * VT_W), load_fe_limbs(T + (size_t)(nlo + hi) * VT_W));                                  // alpha * a * s[i]
-            const Fe nr_lo = load_fe_limbs(T + (size_t)(nlo + nhi + lo) * VT_W), r_hi = load_fe_limbs(T + (size_t)(nlo + nhi + nlo + hi) * VT_W);         // product: -b * s[N-1-i]
-            const Fe yhi = load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * VT_W);
-            const Fe YA = fe_mul<F>(load_fe_limbs(T + (size_t)(3 * (nlo + nhi) + lo) * VT_W), yhi);                                                    // alpha * y^-i
+            const Fe ns_lo = load_fe_limbs(T + (size_t)lo * VT_W), s_hi = load_fe_limbs(T + (size_t)(nlo + hi) * VT_W);                                   // product: -alpha * a * s[i]
+            const Fe nr_lo = load_fe_limbs(T + (size_t)(nlo + nhi + lo) * VT_W), r_hi = load_fe_limbs(T + (size_t)(nlo + nhi + nlo + hi) * VT_W);         // product: -alpha * y^-i * b * s[N-1-i]
             Fe g, h, dl = fe_zero<F>();
             if (i < n) {
+                const Fe yhi = load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + nlo + hi) * VT_W);
+                const Fe YA = fe_mul<F>(load_fe_limbs(T + (size_t)(3 * (nlo + nhi) + lo) * VT_W), yhi);                                                // alpha * y^-i
                 const Fe YX = fe_mul<F>(load_fe_limbs(T + (size_t)(2 * (nlo + nhi) + lo) * VT_W), yhi);                                                // alpha * x * y^-i
                 // columns i of W_L, W_R, W_O in one pass over their entries sorted by constraint index (equal indices reuse the
                 // power); z^(q+1) is one product of two entries of the proof's split table.  The three sums are lazy: a carry pass
                 // and weak reduction after every sixth entry (limbs of <= 7 summed L = 1 terms fit 32 bits).
                 Fe wL = fe_zero<F>(), wR = fe_zero<F>(), wO = fe_zero<F>(), zp = fe_one<F>();
                 u32 cur = 0, since = 0;   // exponent zp holds (0 = none yet; q + 1 >= 1 always)
-                for (u32 e = t.m_off[i], e1 = t.m_off[i + 1]; e < e1; e++) {
-                    const u32 ent = t.m_ent[e], q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
-                    if (q1 != cur) zp = fe_mul<F>(load_fe_limbs(Z + (size_t)(q1 & 255u) * VT_W), load_fe_limbs(Z + (size_t)(256u + (q1 >> 8)) * VT_W));
+                for (u32 x = 0; x < ne; x++) {
+                    const u32 ent = ent_n, cid = cid_n;   // bit 31 of cid: the coefficient is +1, bit 30: it is -1 (most gadget constraints): no product
+                    const Fe zl = zl_n, zh = zh_n;
+                    u32 cw[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) cw[j] = cw_n[j];
+                    if (x + 1 < ne) fetch(x + 1);
+                    const u32 q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
+                    if (q1 != cur) zp = fe_mul<F>(zl, zh);
                     cur = q1;
-                    const u32 cid = t.m_c[e];   // bit 31: the coefficient is +1, bit 30: it is -1 (most gadget constraints): no product
                     Fe term;
                     if (cid & 0x80000000u) term = zp;
                     else if (cid & 0x40000000u) term = fe_neg<F, 2>(zp);
-                    else term = fe_mul<F>(zp, load_fe_dev<F>(coefs + (size_t)cid * 8));
+                    else term = fe_mul<F>(zp, fe_unpack(cw));
                     if (vec == 0) wL = fe_add(wL, term); else if (vec == 1) wR = fe_add(wR, term); else wO = fe_add(wO, term);
                     if (++since == 6) { wL = fe_wred<F>(fe_norm(wL)); wR = fe_wred<F>(fe_norm(wR)); wO = fe_wred<F>(fe_norm(wO)); since = 0; }
                 }
                 wL = fe_norm(wL); wR = fe_norm(wR); wO = fe_norm(wO);   // L = 1, V <= 2 + 6 * 3
                 // alpha * g = alpha*x*y^-i*wR - alpha*a*s[i];  alpha * h = alpha*y^-i * (x*wL + wO - b*s[N-1-i]) - alpha;
-                // alpha*r*x^2 * y^-i*wR*wL = (r*x) * (alpha*x*y^-i*wR) * wL   (verifier.rs:477-500, weighted by the batch's alpha)
-                const Fe Pr = fe_mul<F>(YX, wR);
-                g = fe_sub<F, 2>(Pr, A);
-                const Fe x = load_fe_limbs(K);
-                Fe tt = fe_mul2<F>(x, wL, nr_lo, r_hi);                  // x*wL - b*s[N-1-i]: one reduction for both products
-                tt = fe_norm(fe_add(tt, wO));
-                h = fe_sub<F, 2>(fe_mul<F>(YA, tt), alpha);
-                dl = fe_mul<F>(Pr, wL);
+                // alpha*r*x^2 * y^-i*wR*wL = (r*x) * (alpha*x*y^-i*wL) * wR   (verifier.rs:477-500, weighted by the batch's alpha)
+                g = fe_mul2<F>(YX, wR, ns_lo, s_hi);
+                const Fe M = fe_mul<F>(YX, wL);
+                h = fe_sub<F, 2>(fe_add(fe_mul2<F>(YA, wO, nr_lo, r_hi), M), alpha);   // (V <= 2.3 + 1.7 + 2)
+                dl = fe_mul<F>(M, wR);
             } else {
-                g = fe_neg<F, 2>(A);
-                h = fe_sub<F, 2>(fe_mul<F>(YA, fe_mul<F>(nr_lo, r_hi)), alpha);
+                g = fe_mul<F>(ns_lo, s_hi);
+                h = fe_sub<F, 2>(fe_mul<F>(nr_lo, r_hi), alpha);
             }
             // u_or_1 = 1 for the phase-1 multipliers, u for the randomized-phase ones and on the padding (verifier.rs:486-489)
             if (i >= n1) {
@@ -328,23 +383,10 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
             }
             ag = fe_add(ag, g);
             ah = fe_add(ah, h);
-            // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms;
-            // wcp collects alpha * x * (their sum)
-            Fe wcp = fe_zero<F>();
-            for (u32 e = i; e < t.n_const; e += N) {   // (lanes share the constant terms; a handful per circuit, or one per gate)
-                const u32 cid = t.const_c[e];
-                const u32 q1 = t.const_q[e] + 1u;   // (a constant per gate is common: the range-proof gadget has one per bit) - the split table, not a power ladder
-                const Fe zq = fe_mul<F>(load_fe_limbs(Z + (size_t)(256u + nzhi + (q1 & 255u)) * VT_W), load_fe_limbs(Z + (size_t)(256u + (q1 >> 8)) * VT_W));   // alpha * x * z^(q+1)
-                Fe term;
-                if (cid & 0x80000000u) term = zq;
-                else if (cid & 0x40000000u) term = fe_wred<F>(fe_neg<F, 2>(zq));
-                else term = fe_mul<F>(zq, load_fe_dev<F>(coefs + (size_t)cid * 8));
-                wcp = fe_addr<F>(wcp, term);
-            }
             // alpha*r*x^2 * (y^-i*wR*wL - wc terms) = (r*x) * (alpha*x*y^-i*wR*wL - alpha*x*wc): one product for both
-            if (i < n || t.n_const > i) {
+            if (i < n || has_c0) {
                 Fe tsum;
-                if (i < n && t.n_const > i) tsum = fe_sub<F, 4>(dl, wcp);
+                if (i < n && has_c0) tsum = fe_sub<F, 4>(dl, wcp);
                 else if (i < n) tsum = dl;
                 else tsum = fe_neg<F, 4>(wcp);
                 ad = fe_add(ad, fe_mul<F>(load_fe_limbs(K + 3 * VT_W), tsum));

@@ -516,7 +516,9 @@ def run_prove(args, rank, world, local):
         if rc != -4:
             raise RuntimeError("bench: a tampered copy of timed proof %d was not rejected (status %d)" % (i, rc))
         verified += 1
+    t_chk = time.perf_counter()
     tables_bad = list(engs[0].gens_tables_check()) if (tab_info or msm_tab_info) else None
+    t_chk = time.perf_counter() - t_chk
     if tables_bad and any(tables_bad):
         raise RuntimeError("bench: precomputed table entries fail the chain-rule check: %r" % (tables_bad,))
     coll_info = None
@@ -553,7 +555,7 @@ def run_prove(args, rank, world, local):
                    "constraints_per_proof": N, "proofs_per_step": args.batch, "gpu_streams": P, "host_threads": args.host_threads, "build_threads": args.build_threads,
                    "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
                    "verified": verified, "verified_note": "timed proofs 0 and %d verified on the GPU after the timed region, a tampered copy of each rejected" % (nproofs - 1),
-                   "table_entries_failing_check": tables_bad, "collectives": coll_info,
+                   "table_entries_failing_check": tables_bad, "tables_check_s": t_chk if tables_bad is not None else None, "collectives": coll_info,
                    "pipeline_thread_seconds_per_wall_second": pipe_util, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
@@ -929,8 +931,37 @@ def run_headline(args, rank, world, local):
     res["metric"] = "r1cs_constraints_proved_per_sec (+ r1cs_batch_verifies_per_sec under \"verify\")"
     res["verify"] = ver
     if world > 1 and args.cfg5_logn > 0:
-        res["cfg5"] = run_cfg5(args, rank, world, local)
+        res["cfg5"] = guarded_cfg5(args, rank, world, local, res)
     return res
+
+
+def guarded_cfg5(args, rank, world, local, res):
+    """The cfg5 leg is the one part of the headline run whose collectives no builder box could exercise with more than one GPU (a
+    one-GPU box cannot host two RCCL ranks): a rank failing alone there would leave the others waiting inside a collective and the
+    run without its JSON line.  So the leg runs under a timer: when it fires, rank 0 prints the headline line (prove + verify are
+    complete at this point) with the failure recorded under "cfg5", and every rank leaves."""
+    import threading
+
+    limit = args.cfg5_timeout
+    fallback_line = None
+    if rank == 0:
+        fallback_line = json.dumps(dict(res, cfg5={"error": "the cfg5 leg did not finish within %d s (a rank failed or a collective did not complete); "
+                                                            "prove and verify above are complete" % limit}))
+
+    def bail():
+        if rank == 0:
+            print(fallback_line, flush=True)
+        os._exit(0)
+
+    timer = threading.Timer(limit, bail)
+    timer.daemon = True
+    timer.start()
+    try:
+        out = run_cfg5(args, rank, world, local)
+    except Exception as exc:       # (this rank failed alone: the others leave through their timers)
+        out = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:400]), "rank": rank}
+    timer.cancel()
+    return out
 
 
 def main():
@@ -958,6 +989,7 @@ def main():
     ap.add_argument("--sweep-one-curve", action="store_true", help="shuffle-sweep workload: only --curve (default: secq256k1 and zorro)")
     ap.add_argument("--cfg5-logn", type=int, default=22, help="headline with --gpus N > 1: size of the window-sharded proofs of the cfg5 leg (0 = skip the leg)")
     ap.add_argument("--cfg5-steps", type=int, default=2, help="steps (of 8 proofs) of the cfg5 leg")
+    ap.add_argument("--cfg5-timeout", type=int, default=600, help="seconds after which the cfg5 leg is given up and the headline line printed without it")
     ap.add_argument("--tables-off-steps", type=int, default=4, help="prove workload: timed steps of the same pipeline with the precomputed tables released (0 = skip)")
     ap.add_argument("--fold-table-bits", type=int, default=0, help="window width of those tables (0 = the widest that fits in 3/4 of the free HBM)")
     ap.add_argument("--terms", type=int, default=1 << 16)
@@ -979,6 +1011,8 @@ def main():
     res = {"msm": run_msm, "prove": run_prove, "verify": run_verify, "headline": run_headline, "shuffle-sweep": run_shuffle_sweep}[args.workload](args, rank, world, local)
     if rank == 0:
         print(json.dumps(res), flush=True)
+    if isinstance(res, dict) and isinstance(res.get("cfg5"), dict) and "error" in res["cfg5"]:
+        os._exit(0)        # (the other ranks may still sit in a collective of the failed leg: no orderly teardown is possible)
     if world > 1:
         import torch.distributed as dist
 
