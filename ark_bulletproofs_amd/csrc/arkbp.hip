@@ -214,6 +214,7 @@ struct bp_ctx {
     size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
     size_t tune_host_threads = 0;                  // BP_TUNE_HOST_THREADS: size of this ctx's host pool (0 = host_pool_threads())
     bool msm_latency_first = false;                // set by the bp_msm* entry points for the duration of the call (see msm_use_quad)
+    size_t tune_msm_chunk_cap = 0;                 // BP_TUNE_MSM_CHUNK_CAP: entries per level-1 chunk of the fixed-shape MSM pipeline (0 = fs_chunk_cap's choice)
     size_t tune_fold_quad_max = 0;                 // BP_TUNE_FOLD_QUAD_MAX: fold rounds with at most this many output points run four lanes per point (0 = never)
     size_t tune_msm_glv_min = 256;                 // BP_TUNE_MSM_GLV_MIN: terms from which an MSM on a GLV curve splits its scalars
     DevBuf cyc_a, cyc_b, cyc_Gf, cyc_Hf;
@@ -345,6 +346,7 @@ static bool msm_use_quad(const bp_ctx* ctx) { const int e = msm_latency_env(); r
 static u32 fs_chunk_cap(const bp_ctx* ctx, double binned_entries, double binned_buckets, double top_entries, double top_buckets) {
     static const int cap_env = getenv("ARKBP_MSM_FS_CAP") ? atoi(getenv("ARKBP_MSM_FS_CAP")) : 0;   // experiments
     if (cap_env >= 8 && cap_env <= 64) return (u32)cap_env;
+    if (ctx->tune_msm_chunk_cap) return (u32)ctx->tune_msm_chunk_cap;
     if (!msm_use_quad(ctx) || binned_buckets < 1.0) return 1u << MSM_CHL_BINNED;
     const double lanes_per_fill = 256.0 * 4 * 64;   // one wave on every SIMD of the chip
     const double mu = binned_entries / binned_buckets, sd = std::sqrt(std::max(mu, 1e-9));
@@ -2335,6 +2337,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
         case BP_TUNE_MSM_WSUM_MIN: c->tune_msm_wsum_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_GLV_MIN: c->tune_msm_glv_min = (size_t)value; return BP_OK;
         case BP_TUNE_FOLD_QUAD_MAX: c->tune_fold_quad_max = (size_t)value; return BP_OK;
+        case BP_TUNE_MSM_CHUNK_CAP: if (value && (value < 8 || value > 64)) return BP_E_ARG; c->tune_msm_chunk_cap = (size_t)value; return BP_OK;
     }
     return BP_E_ARG;
 }

@@ -410,6 +410,8 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
                                      point (quad-cooperative group arithmetic): shorter rounds, more arithmetic; default 0 = never (a prover that keeps the GPU
                                      full gains nothing); a latency-bound single prover sets 2^14 */
 #define BP_TUNE_MSM_GLV_MIN 7     /* terms from which a variable-base MSM on secq256k1 splits its scalars with the endomorphism (default 256; a huge value turns it off) */
+#define BP_TUNE_MSM_CHUNK_CAP 9   /* entries per first-level chunk of the mid-size (fixed-shape) MSM pipeline: 8 .. 64; 0 = default (16 for callers that keep
+                                     the GPU full; fitted per MSM to whole waves per SIMD for the bp_msm* entry points).  Results never depend on it */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 
 /* The O(N) part of `Verifier::verification_scalars` (src/r1cs/verifier.rs:465-514, s from inner_product_proof.rs:279-311) for a

@@ -445,3 +445,32 @@ def test_msm_glv_split_schedule_matches_ordinary_and_oracle(oracle):
         assert (a == b).all() and (a == O.msm(cv, G, sc)).all()
     finally:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cv", [0, 1])
+def test_msm_chunk_sizes_of_the_fixed_shape_pipeline(oracle, cv):
+    """BP_TUNE_MSM_CHUNK_CAP: the mid-size MSM pipeline cuts every bucket into ceil(population / cap) chunks that share its entries
+    evenly; any cap from 8 to 64 must give the same point (a sum of the same group elements) — also with a few heavy buckets (repeated
+    scalars: up to 32 partials per bucket reach the one-step reduction), and at both ends of the range the knob accepts."""
+    import ark_bulletproofs_amd as A
+
+    O = oracle
+    FR = O.fid(cv, True)
+    e = A.Engine(curve=cv)
+    try:
+        for n in (700, 6000):
+            G, H = O.bp_gens(cv, n // 2 + 1)
+            bases = np.concatenate([G, H])[:n]
+            sc = O.fe_rand(FR, bytes([n % 199, cv]) * 16, n)
+            sc[10:150] = sc[3]               # one scalar 140 times: the same bucket of every window holds 140 of its entries
+            sc[200:230] = O.fe_from_int(FR, 1)
+            want = O.msm(cv, bases, sc)
+            for cap in (0, 8, 9, 11, 12, 13, 16, 21, 32, 64):
+                e.set_tuning(9, cap)
+                assert (e.msm(bases, sc) == want).all(), (n, cap)
+        for bad in (1, 7, 65):
+            with pytest.raises(Exception):
+                e.set_tuning(9, bad)
+    finally:
+        e.close()
