@@ -1341,8 +1341,8 @@ template <class C> static int launch_tab_fold2(bp_ctx* ctx, const IpaState& s, u
     typedef host::Fld<typename C::Fr> S;
     done = false;
     FtabDigits3 dG, dH;
-    if (!ftab_digits<C>(ctx, s.def_tG, dG.d1) || !ftab_digits<C>(ctx, t2G, dG.d2) || !ftab_digits<C>(ctx, S::mul(s.def_tG, t2G), dG.d12)) return BP_OK;
-    if (!ftab_digits<C>(ctx, s.def_tH, dH.d1) || !ftab_digits<C>(ctx, t2H, dH.d2) || !ftab_digits<C>(ctx, S::mul(s.def_tH, t2H), dH.d12)) return BP_OK;
+    if (!ftab_digits<C>(ctx, s.def_tG, dG.d[0]) || !ftab_digits<C>(ctx, t2G, dG.d[1]) || !ftab_digits<C>(ctx, S::mul(s.def_tG, t2G), dG.d[2])) return BP_OK;
+    if (!ftab_digits<C>(ctx, s.def_tH, dH.d[0]) || !ftab_digits<C>(ctx, t2H, dH.d[1]) || !ftab_digits<C>(ctx, S::mul(s.def_tH, t2H), dH.d[2])) return BP_OK;
     const u32 lanes = (u32)(2 * m);
     FoldFinish ff;
     BPCHK(fold_finish_plan(ctx, lanes, ff));

@@ -216,9 +216,12 @@ def pmc_traffic(keys, applicable, fname, field="largest"):
         d = json.load(open(f3 if os.path.exists(f3) else os.path.join(ROOT, "profiles", fname)))
         tot, found = 0.0, 0
         for k in ([keys] if isinstance(keys, str) else keys):
-            if k in d:      # (a kernel the profiled configuration did not launch contributes nothing)
-                tot += (2.0 * d[k]["fetch_KiB_" + field] + d[k]["write_KiB_" + field]) * 1024.0
-                found += 1
+            # (a kernel the profiled configuration did not launch contributes nothing; "name<Curve>" also stands for the
+            # instantiations with further template arguments, "name<Curve, false>")
+            for kk in d:
+                if kk == k or kk.startswith(k[:-1] + ","):
+                    tot += (2.0 * d[kk]["fetch_KiB_" + field] + d[kk]["write_KiB_" + field]) * 1024.0
+                    found += 1
         return tot if found else None
     except Exception:
         return None
@@ -616,14 +619,15 @@ def run_prove(args, rank, world, local):
         ]
         # the two accumulate rows share the proof's MSM terms: algorithmic bytes and products for their sum
         acc_all_ms = acc_ms + accfs_ms
-        res["roofline"] = {"bound": "hbm", "kernel": "IPA G/H fold (k_ipa_fold_tab [round 1] + k_ipa_fold_glv + k_ipa_fold_finish + k_ipa_fold_ab), all rounds of one proof",
+        res["roofline"] = {"bound": "hbm", "kernel": "IPA G/H fold (k_ipa_fold_tab / k_ipa_fold_tab2 [rounds from the tables] + k_ipa_fold_glv + k_ipa_fold_finish + k_ipa_fold_ab), all rounds of one proof",
                            "per": "one 2^%d proof (all launches of the kernel group), run alone after the timed region" % args.logn,
                            "achieved": 576.0 * (N - 1) / per_proof_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 576.0 * (N - 1) / per_proof_s / 1e9 / HBM_PEAK_GBS,
                            # HBM bytes of all fold launches of ONE proof (same unit as `achieved`), from the committed PMC passes of this shape
-                           "traffic": tr(["prove2p20/k_ipa_fold_glv<Secq>", "prove2p20/k_ipa_fold_tab<Secq>", "prove2p20/k_ipa_fold_finish<Secq>", "prove2p20/k_ipa_fold_ab<Secq>"]),
-                           "traffic_note": "traffic above the algorithmic bytes is deliberate here: ~2.2 GB of table rows streamed by round 1 (instead of 12 ms of ladder "
-                                           "arithmetic) and 0.58 GB of Jacobian results written by the ladders and re-read by k_ipa_fold_finish; together < 0.5 ms at HBM speed",
+                           "traffic": tr(["prove2p20/k_ipa_fold_glv<Secq>", "prove2p20/k_ipa_fold_tab<Secq>", "prove2p20/k_ipa_fold_tab2<Secq>", "prove2p20/k_ipa_fold_finish<Secq>", "prove2p20/k_ipa_fold_ab<Secq>"]),
+                           "traffic_note": "traffic above the algorithmic bytes is deliberate here: the table rows streamed by the rounds that come from the tables (34 rows x 64 B per "
+                                           "point and multiplier, instead of ~20 ms of ladder arithmetic) and the Jacobian results written by the ladders and re-read by "
+                                           "k_ipa_fold_finish; together < 1 ms at HBM speed",
                            "avg_kernel_ms": fold_ms / max(fold_n, 1), "fold_ms_per_proof": fold_ms,
                            "msm_kernels_ms_per_proof": msm_ms, "msm_accum_ms_per_proof": acc_all_ms,
                            "valu": valu_entry(modmul, per_proof_s, "the path is integer-VALU-bound: this is the fraction that measures the kernels — modular products the fold "
