@@ -468,6 +468,9 @@ def run_prove(args, rank, world, local):
         tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0, "bases": tab_count, "rounds_from_tables": 2 if tab_count > N // 2 else 1}
     for e in engs[1:]:
         e.share_gens_from(engs[0])
+    if getattr(args, "freeze_len", 0):
+        for e in engs:
+            e.set_tuning(2, args.freeze_len)
     if window_sharded:
         # north_star / cfg5 partition: all ranks prove the SAME statements; every MSM inside prove() accumulates the rank's Pippenger
         # windows and the partial points are summed over RCCL (strong scaling of one proof at a time: one proof in flight, because
@@ -994,6 +997,7 @@ def main():
     ap.add_argument("--cfg5-logn", type=int, default=22, help="headline with --gpus N > 1: size of the window-sharded proofs of the cfg5 leg (0 = skip the leg)")
     ap.add_argument("--cfg5-steps", type=int, default=2, help="steps (of 8 proofs) of the cfg5 leg")
     ap.add_argument("--cfg5-timeout", type=int, default=600, help="seconds after which the cfg5 leg is given up and the headline line printed without it")
+    ap.add_argument("--freeze-len", type=int, default=0, help="prove workload: BP_TUNE_IPA_FREEZE_LEN of every ctx (0 = the library's default)")
     ap.add_argument("--tables-off-steps", type=int, default=4, help="prove workload: timed steps of the same pipeline with the precomputed tables released (0 = skip)")
     ap.add_argument("--fold-table-bits", type=int, default=0, help="window width of those tables (0 = the widest that fits in 3/4 of the free HBM)")
     ap.add_argument("--terms", type=int, default=1 << 16)

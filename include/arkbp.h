@@ -395,7 +395,7 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
  * large-input paths with small inputs).  FOLD_BATCH_MIN: output points per IPA fold round from which the affine conversion
  * shares inversions (default 65536); MSM_BIN_MIN: terms from which the MSM uses the two-level sort (default 64);
  * IPA_FREEZE_LEN: vector length from which bp_ipa_create / the prover stop folding G and H and fold per-element coefficients
- * over the frozen vectors instead (default 1024; 0 or 1 = never); MSM_WSUM_MIN: total bucket count from which an MSM aggregates
+ * over the frozen vectors instead (default 8192; 0 or 1 = never); MSM_WSUM_MIN: total bucket count from which an MSM aggregates
  * its buckets by running sums instead of bit marginals (default 2^18). */
 #define BP_TUNE_FOLD_BATCH_MIN 0
 #define BP_TUNE_MSM_BIN_MIN 1
