@@ -192,3 +192,37 @@ def test_product_transcript_rng_matches_independent_model(E, curve):
             exp = model(seeds8[32 * j: 32 * j + 32], 12)
             vals = [v for v in ints(got8[j]) if v < p]
             assert vals[: len(vals)] == exp[: len(vals)] and len(vals) >= 10
+
+
+def test_bench_cfg5_leg_cannot_cost_the_run_its_json_line():
+    """bench.py's multi-GPU headline run adds the partitioned 2^22 proof as a third leg whose collectives no one-GPU box can
+    exercise.  If that leg hangs (a rank failed alone, a collective never completes) or raises, rank 0 must still print the
+    headline line — prove and verify are complete by then — with the failure recorded under "cfg5"."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import sys, time, json, argparse
+sys.path.insert(0, %r)
+import bench
+mode = sys.argv[1]
+def fake(args, rank, world, local):
+    if mode == "hang":
+        time.sleep(60)
+    raise RuntimeError("rank failed in the cfg5 leg")
+bench.run_cfg5 = fake
+args = argparse.Namespace(cfg5_timeout=1)
+res = {"metric": "m", "value": 1.0, "verify": {"value": 2.0}}
+res["cfg5"] = bench.guarded_cfg5(args, 0, 2, 0, res)
+print(json.dumps(res), flush=True)
+""" % root
+    for mode in ("hang", "raise"):
+        out = subprocess.run([sys.executable, "-c", prog, mode], capture_output=True, text=True, timeout=50)
+        assert out.returncode == 0, out.stderr[-500:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        d = json.loads(lines[0])
+        assert d["value"] == 1.0 and d["verify"]["value"] == 2.0 and "error" in d["cfg5"], d
