@@ -316,14 +316,23 @@ template <class P> ARKBP_HD void fe_store_dev(u32 w[8], const Fe& a) { fe_pack(w
 
 // a^(p-2) (0 -> 0); input/outputs L = 1, V <= 2.  Off the per-element path: kernels batch inversions.
 template <class P> ARKBP_HD Fe fe_inv(const Fe& a) {
+    // a^(p-2), two exponent bits per step (a, a^2, a^3 at hand): p - 2 is mostly ones for these moduli, and a digit 3 costs ONE
+    // product for two bits: 256 squarings + ~125 products instead of ~250
+    const Fe a2 = fe_sqr<P>(a), a3 = fe_mul<P>(a2, a);
     Fe r = fe_one<P>();
-#pragma unroll
+#pragma unroll 1
     for (int w = 7; w >= 0; w--) {
         const u32 e = P::PM2[w];
 #pragma unroll 1
-        for (int i = 31; i >= 0; i--) {
-            r = fe_sqr<P>(r);
-            if ((e >> i) & 1) r = fe_mul<P>(r, a);
+        for (int i = 30; i >= 0; i -= 2) {
+            r = fe_sqr<P>(fe_sqr<P>(r));
+            const u32 d = (e >> i) & 3u;
+            if (d) {
+                Fe m;
+#pragma unroll
+                for (int j = 0; j < 9; j++) m.l[j] = d == 1u ? a.l[j] : d == 2u ? a2.l[j] : a3.l[j];
+                r = fe_mul<P>(r, m);
+            }
         }
     }
     return r;

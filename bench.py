@@ -979,7 +979,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm", "shuffle-sweep"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
-    ap.add_argument("--verify-inflight", type=int, default=3, help="verify workload: batch_verify calls in flight per GPU (own ctx and host pool each; the pools divide the process's CPU quota)")
+    ap.add_argument("--verify-inflight", type=int, default=4, help="verify workload: batch_verify calls in flight per GPU (own ctx and host pool each; the pools divide the process's CPU quota)")
     ap.add_argument("--shuffle-k", type=int, default=0, help="verify workload: batches of k-shuffle proofs (the reference's two-phase benchmark circuit) instead of cfg4's range proofs")
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
