@@ -65,9 +65,10 @@ template <int K> ARKBP_HD Fe fe_times(const Fe& a) {
     return fe_norm(r);
 }
 
+// (no identity branch: Z3 = 2*Y*Z is exactly zero when Z is, so the identity doubles to an identity with whatever X, Y — only
+// Z == 0 marks it)
 template <class C> ARKBP_HD Jac jac_dbl(const Jac& p) {
     typedef typename C::Fq F;
-    if (jac_is_inf(p)) return p;
     Jac o;
     if (C::A_ZERO) {
         // dbl-2009-l shape: A = X^2, B = Y^2, C = B^2, D = 4XB, E = 3A, X3 = E^2 - 2D, Y3 = E(D - X3) - 8C, Z3 = 2YZ
@@ -116,6 +117,31 @@ template <class C> ARKBP_HD Jac jac_madd(const Jac& p, const Aff& q) {
         if (fe_is_zero_mod<F>(r)) return jac_dbl<C>(p);
         return jac_inf<C>();
     }
+    Fe HH = fe_sqr<F>(H);           // <= 1.8
+    Fe HHH = fe_mul<F>(H, HH);      // <= 1.3
+    Fe V = fe_mul<F>(p.X, HH);      // <= 1.2
+    Jac o;
+    o.X = fe_wred<F>(fe_sub<F, 4>(fe_sqr<F>(r), fe_add(HHH, fe_dbl(V))));
+    Fe Y3 = fe_mul<F>(r, fe_sub<F, 4>(V, o.X));
+    o.Y = fe_wred<F>(fe_sub<F, 2>(Y3, fe_mul<F>(p.Y, HHH)));
+    o.Z = fe_mul<F>(p.Z, H);
+    return o;
+}
+
+// The hot form of the mixed addition, for loops that add many points: the incomplete formulas as ONE basic block, and `rare` set
+// when an operand is the identity or the points may be equal / opposite (the low-limb filter of fe_is_zero_mod on H: no false
+// negatives) — the result is then meaningless and the caller redoes the addition with jac_madd.  With the exceptional returns
+// inlined in the middle of jac_madd the register allocator spends ~400 moves per addition on them (hipcc -S of an accumulate-shaped
+// loop: 3 340 VALU instructions per iteration against 2 680 for this form + a cold block); callers keep p alive (nine more
+// registers) and read q again in the cold block.
+template <class C> ARKBP_HD Jac jac_madd_fast(const Jac& p, const Aff& q, bool& rare) {
+    typedef typename C::Fq F;
+    Fe Z1Z1 = fe_sqr<F>(p.Z);
+    Fe U2 = fe_mul<F>(q.x, Z1Z1);
+    Fe S2 = fe_mul<F>(q.y, fe_mul<F>(p.Z, Z1Z1));
+    Fe H = fe_sub<F, 4>(U2, p.X);   // V <= 5.1
+    Fe r = fe_sub<F, 4>(S2, p.Y);
+    rare = aff_is_inf(q) | jac_is_inf(p) | fe_maybe_zero_mod<F>(H);
     Fe HH = fe_sqr<F>(H);           // <= 1.8
     Fe HHH = fe_mul<F>(H, HH);      // <= 1.3
     Fe V = fe_mul<F>(p.X, HH);      // <= 1.2

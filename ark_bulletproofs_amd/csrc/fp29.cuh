@@ -27,9 +27,11 @@
 #include <hip/hip_runtime.h>
 #define ARKBP_HD __host__ __device__ __forceinline__
 #define ARKBP_DEV_NOINLINE __device__ __noinline__
+#define ARKBP_HD_NOINLINE __host__ __device__ __noinline__
 #else
 #define ARKBP_HD inline
 #define ARKBP_DEV_NOINLINE inline
+#define ARKBP_HD_NOINLINE inline
 #endif
 #include "arkbp_params.h"
 
@@ -266,7 +268,7 @@ template <class P> ARKBP_HD Fe fe_canon(const Fe& a) {
 
 // a == 0 (mod p)?   Needs L = 1, V < 32.  Cheap filter on the low limb first: a = k*p forces
 // a_0 = k*p_0 mod 2^29 with k within one of the top-limb estimate; the exact test runs only then.
-template <class P> ARKBP_HD bool fe_is_zero_mod(const Fe& a) {
+template <class P> ARKBP_HD bool fe_maybe_zero_mod(const Fe& a) {   // the filter alone: false means a != 0 (mod p) for certain
     constexpr int sh = P::WR_BITS - 232;
     const u32 q = a.l[8] >> sh;
     bool maybe = false;
@@ -275,7 +277,10 @@ template <class P> ARKBP_HD bool fe_is_zero_mod(const Fe& a) {
         const u32 k = q + (u32)d;
         maybe |= (a.l[0] == ((k * P::P29[0]) & M29));
     }
-    if (!maybe) return false;
+    return maybe;
+}
+template <class P> ARKBP_HD bool fe_is_zero_mod(const Fe& a) {
+    if (!fe_maybe_zero_mod<P>(a)) return false;
     return fe_is_zero_exact(fe_canon<P>(a));
 }
 template <class P> ARKBP_HD bool fe_eq_mod(const Fe& a, const Fe& b) {  // L = 1 both, V(b) < 16

@@ -401,9 +401,17 @@ k_ipa_fold_pts(u32* __restrict__ G, u32* __restrict__ H, const u32* __restrict__
 struct Naf {
     u32 plus[9], minus[9];
 };
+// acc + T in the ladders and table folds: the one-block form, redone with the complete formulas in the rare exceptional cases
+// (ec.cuh jac_madd_fast); T stays in registers there
+template <class C> __device__ __forceinline__ Jac ladder_madd(const Jac& acc, const Aff& T) {
+    bool rare;
+    Jac nxt = jac_madd_fast<C>(acc, T, rare);
+    if (__builtin_expect(rare, 0)) nxt = jac_madd<C>(acc, T);
+    return nxt;
+}
 // QUAD: four lanes (a DPP quad) share one point's ladder (ecq.cuh) — for the rounds whose points do not fill the chip; lane 0 of
 // the quad emits.
-template <class C, bool QUAD = false> __global__ void __launch_bounds__(256)
+template <class C, bool QUAD = false> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf tH, int which /* 1: G only, 2: H only, 3: both */,
                    u32* __restrict__ jac_ws) {
     const u32 tl = blockIdx.x * blockDim.x + threadIdx.x;
@@ -421,8 +429,10 @@ k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf 
 #pragma unroll 1
         for (int bit = (wd == 8 ? 0 : 31); bit >= 0; bit--) {
             acc = QUAD ? qjac_dbl<C>(acc, ql) : jac_dbl<C>(acc);
-            if ((ep >> bit) & 1) acc = QUAD ? qjac_madd<C>(acc, P1, ql) : jac_madd<C>(acc, P1);
-            else if ((em >> bit) & 1) acc = QUAD ? qjac_madd<C>(acc, N1, ql) : jac_madd<C>(acc, N1);
+            if (((ep | em) >> bit) & 1) {   // ONE addition site: the digit's sign picks y (wave-uniform)
+                Aff T1 = P1; T1.y = ((em >> bit) & 1) ? N1.y : P1.y;
+                acc = QUAD ? qjac_madd<C>(acc, T1, ql) : ladder_madd<C>(acc, T1);
+            }
         }
     }
     acc = QUAD ? qjac_madd<C>(acc, P2, ql) : jac_madd<C>(acc, P2);
@@ -435,7 +445,7 @@ k_ipa_fold_uniform(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf tG, Naf 
 struct Naf2 {
     u32 p1[5], m1[5], p2[5], m2[5];   // bit i: digit +1 / -1 at 2^i of t1 (p1/m1) and t2 (p2/m2), 130 digits
 };
-template <class C, bool QUAD = false> __global__ void __launch_bounds__(256)
+template <class C, bool QUAD = false> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH, int which /* 1: G only, 2: H only, 3: both */,
                u32* __restrict__ jac_ws) {
     typedef typename C::Fq F;
@@ -458,8 +468,21 @@ k_ipa_fold_glv(u32* __restrict__ G, u32* __restrict__ H, u32 n, Naf2 tG, Naf2 tH
 #pragma unroll 1
         for (int bit = (wd == 4 ? 1 : 31); bit >= 0; bit--) {
             acc = QUAD ? qjac_dbl<C>(acc, ql) : jac_dbl<C>(acc);
-            if (((a | b) >> bit) & 1) { Aff T1 = P1; T1.y = ((b >> bit) & 1) ? N1.y : P1.y; acc = QUAD ? qjac_madd<C>(acc, T1, ql) : jac_madd<C>(acc, T1); }   // masks are wave-uniform
-            if (((c | d) >> bit) & 1) { Aff T2 = Q1; T2.y = ((d >> bit) & 1) ? N1.y : P1.y; acc = QUAD ? qjac_madd<C>(acc, T2, ql) : jac_madd<C>(acc, T2); }
+            if (QUAD) {
+                if (((a | b) >> bit) & 1) { Aff T1 = P1; T1.y = ((b >> bit) & 1) ? N1.y : P1.y; acc = qjac_madd<C>(acc, T1, ql); }   // masks are wave-uniform
+                if (((c | d) >> bit) & 1) { Aff T2 = Q1; T2.y = ((d >> bit) & 1) ? N1.y : P1.y; acc = qjac_madd<C>(acc, T2, ql); }
+            } else {
+#pragma unroll 1
+                for (int h = 0; h < 2; h++) {   // ONE addition site for both halves (the masks are wave-uniform)
+                    const u32 nz = h ? (c | d) : (a | b), ng = h ? d : b;
+                    if ((nz >> bit) & 1) {
+                        Aff T;
+#pragma unroll
+                        for (int l = 0; l < 9; l++) { T.x.l[l] = h ? Q1.x.l[l] : P1.x.l[l]; T.y.l[l] = ((ng >> bit) & 1) ? N1.y.l[l] : P1.y.l[l]; }
+                        acc = ladder_madd<C>(acc, T);
+                    }
+                }
+            }
         }
     }
     acc = QUAD ? qjac_madd<C>(acc, P2, ql) : jac_madd<C>(acc, P2);
@@ -588,7 +611,30 @@ k_fb_rows_check(const u32* __restrict__ gens, const u32* __restrict__ T, u32 n, 
 
 // the first-round uniform fold from the tables: lane t -> V[i] = V[n+i] + t_V * Base(g_first + i*g_stride), V = G (lanes [0, n)) or H.
 // G, H: the working vectors (their upper halves are read, their lower halves written — or the Jacobian workspace, see fold_emit).
-template <class C> __global__ void __launch_bounds__(256)
+// one window of a fixed-base multiplication: acc += (+-) e1 * 2^(w*j) * Base[gi] (+ the GLV half: (+-) e2 * 2^(w*j) * phi(Base[gi])),
+// digits wave-uniform.  ONE addition site for both halves; the table entry is read again in the rare exceptional case.
+template <class C> __device__ __forceinline__ Jac ftab_step(Jac acc, const u32* __restrict__ T, u32 n_tab, u32 E, u32 gi, u32 j, u32 e1, u32 e2, bool neg1, bool neg2) {
+    typedef typename C::Fq F;
+#pragma unroll 1
+    for (int h = 0; h < (C::HAS_GLV ? 2 : 1); h++) {
+        const u32 e = h ? e2 : e1;
+        if (!e) continue;
+        const u32* src = T + (((size_t)j * E + (e - 1)) * n_tab + gi) * 16;
+        const bool neg = h ? neg2 : neg1;
+        Aff P = load_aff_dev(src);
+        if constexpr (C::HAS_GLV) { if (h && !aff_is_inf(P)) P.x = fe_mul<F>(P.x, fe_const<F, C::BETA29>()); }   // phi(x, y) = (beta * x, y)
+        bool rare;
+        Jac nxt = jac_madd_fast<C>(acc, aff_cneg_lazy<C>(P, neg), rare);
+        if (__builtin_expect(rare, 0)) {
+            Aff Q = load_aff_dev(src);
+            if constexpr (C::HAS_GLV) { if (h && !aff_is_inf(Q)) Q.x = fe_mul<F>(Q.x, fe_const<F, C::BETA29>()); }
+            nxt = jac_madd<C>(acc, aff_cneg_lazy<C>(Q, neg));
+        }
+        acc = nxt;
+    }
+    return acc;
+}
+template <class C> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 k_ipa_fold_tab(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_tab, u32 E, u32* __restrict__ G, u32* __restrict__ H, u32 n, FtabDigits dG,
                FtabDigits dH, int which, u32 g_first, u32 g_stride, u32* __restrict__ jac_ws,
                const u32* __restrict__ Gin /* nullable: read the upper halves from here (the resident generator tables) instead of G / H */,
@@ -606,17 +652,7 @@ k_ipa_fold_tab(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_tab
 #pragma unroll 1
     for (u32 j = 0; j < nwin; j++) {
         const u32 e1 = isH ? dH.e1[j] : dG.e1[j], e2 = isH ? dH.e2[j] : dG.e2[j];
-        if (e1) {
-            const Aff P = load_aff_dev(T + (((size_t)j * E + (e1 - 1)) * n_tab + gi) * 16);
-            acc = jac_madd<C>(acc, aff_cneg_lazy<C>(P, (((isH ? dH.neg1 : dG.neg1) >> j) & 1ull) != 0));
-        }
-        if constexpr (C::HAS_GLV) {
-            if (e2) {
-                Aff Q = load_aff_dev(T + (((size_t)j * E + (e2 - 1)) * n_tab + gi) * 16);
-                if (!aff_is_inf(Q)) Q.x = fe_canon<F>(fe_mul<F>(Q.x, fe_const<F, C::BETA29>()));   // phi(x, y) = (beta * x, y)
-                acc = jac_madd<C>(acc, aff_cneg_lazy<C>(Q, (((isH ? dH.neg2 : dG.neg2) >> j) & 1ull) != 0));
-            }
-        } else { (void)e2; }
+        acc = ftab_step<C>(acc, T, n_tab, E, gi, j, e1, e2, (((isH ? dH.neg1 : dG.neg1) >> j) & 1ull) != 0, (((isH ? dH.neg2 : dG.neg2) >> j) & 1ull) != 0);
     }
     const u32* Vin = isH ? (Hin ? Hin : H) : (Gin ? Gin : G);
     acc = jac_madd<C>(acc, load_aff_dev(Vin + (size_t)(n + i) * 16));
@@ -638,7 +674,7 @@ struct FtabDigits3 {
 // ONE loop body for the three multipliers, and the digit words are selected field by field: a whole-struct select
 // (isH ? dH.d[k] : dG.d[k]) makes a private copy of the kernel arguments — 1.2 KB of scratch per lane, 1.3 GB of scratch traffic
 // per proof, measured as 0.66 GB of HBM writes in the first version of this kernel.
-template <class C> __global__ void __launch_bounds__(256)
+template <class C> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 k_ipa_fold_tab2(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_tab, u32 E, u32* __restrict__ G, u32* __restrict__ H, u32 m, FtabDigits3 dG,
                 FtabDigits3 dH, u32* __restrict__ jac_ws, const u32* __restrict__ Gin, const u32* __restrict__ Hin) {
     typedef typename C::Fq F;
@@ -657,17 +693,7 @@ k_ipa_fold_tab2(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_ta
 #pragma unroll 1
         for (u32 j = 0; j < nwin; j++) {
             const u32 e1 = isH ? dH.d[mu].e1[j] : dG.d[mu].e1[j], e2 = isH ? dH.d[mu].e2[j] : dG.d[mu].e2[j];
-            if (e1) {
-                const Aff P = load_aff_dev(T + (((size_t)j * E + (e1 - 1)) * n_tab + gi) * 16);
-                acc = jac_madd<C>(acc, aff_cneg_lazy<C>(P, ((neg1 >> j) & 1ull) != 0));
-            }
-            if constexpr (C::HAS_GLV) {
-                if (e2) {
-                    Aff Q = load_aff_dev(T + (((size_t)j * E + (e2 - 1)) * n_tab + gi) * 16);
-                    if (!aff_is_inf(Q)) Q.x = fe_canon<F>(fe_mul<F>(Q.x, fe_const<F, C::BETA29>()));   // phi(x, y) = (beta * x, y)
-                    acc = jac_madd<C>(acc, aff_cneg_lazy<C>(Q, ((neg2 >> j) & 1ull) != 0));
-                }
-            } else { (void)e2; (void)neg2; }
+            acc = ftab_step<C>(acc, T, n_tab, E, gi, j, e1, e2, ((neg1 >> j) & 1ull) != 0, ((neg2 >> j) & 1ull) != 0);
         }
     }
     acc = jac_madd<C>(acc, load_aff_dev((isH ? Hin : Gin) + (size_t)(n + m + i) * 16));

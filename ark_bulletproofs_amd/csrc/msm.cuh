@@ -582,7 +582,8 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
     Jac acc = jac_inf<C>();
     if (beg < end) {
         // the gather of entry e+1 (entry word, then a 64-byte base somewhere in a table far larger than L2) is issued before the
-        // mixed add of entry e, so its latency hides behind ~3 k VALU instructions instead of stalling the lane
+        // mixed add of entry e, so its latency hides behind ~3 k VALU instructions instead of stalling the lane.  The first entry is
+        // lifted, not added; the additions run the one-block form and redo the rare exceptional ones (ec.cuh jac_madd_fast).
         u32 ent = entries[beg];
         Aff p = load_aff_dev(seg_base_ptr(segs, ent >> 1));
         for (u32 e = beg; e < end; e++) {
@@ -592,7 +593,15 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
                 ent_n = entries[e + 1];
                 p_n = load_aff_dev(seg_base_ptr(segs, ent_n >> 1));
             }
-            acc = jac_madd<C>(acc, aff_cneg_lazy<C>(p, ent & 1));
+            if (e == beg) {
+                acc = jac_from_aff<C>(aff_cneg_lazy<C>(p, ent & 1));
+                acc.Y = fe_wred<typename C::Fq>(acc.Y);
+            } else {
+                bool rare;
+                Jac nxt = jac_madd_fast<C>(acc, aff_cneg_lazy<C>(p, ent & 1), rare);
+                if (__builtin_expect(rare, 0)) nxt = jac_madd<C>(acc, aff_cneg_lazy<C>(load_aff_dev(seg_base_ptr(segs, ent >> 1)), ent & 1));
+                acc = nxt;
+            }
             ent = ent_n;
             p = p_n;
         }
@@ -998,7 +1007,21 @@ k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __rest
             if constexpr (C::HAS_GLV) {   // odd half-terms of a split scalar stand for phi(base) = (beta * x, y)
                 if (segs.glv && (ent & 2u) && !aff_is_inf(p)) p.x = fe_mul<typename C::Fq>(p.x, fe_const<typename C::Fq, C::BETA29>());
             }
-            acc = jac_madd<C>(acc, aff_cneg_lazy<C>(p, ent & 1));
+            if (e == beg) {     // the first entry is lifted, not added
+                acc = jac_from_aff<C>(aff_cneg_lazy<C>(p, ent & 1));
+                acc.Y = fe_wred<typename C::Fq>(acc.Y);
+            } else {            // one-block additions; the rare exceptional ones are redone with the complete formulas (ec.cuh jac_madd_fast)
+                bool rare;
+                Jac nxt = jac_madd_fast<C>(acc, aff_cneg_lazy<C>(p, ent & 1), rare);
+                if (__builtin_expect(rare, 0)) {
+                    Aff q = load_aff_dev(seg_base_ptr(segs, ent >> 1));
+                    if constexpr (C::HAS_GLV) {
+                        if (segs.glv && (ent & 2u) && !aff_is_inf(q)) q.x = fe_mul<typename C::Fq>(q.x, fe_const<typename C::Fq, C::BETA29>());
+                    }
+                    nxt = jac_madd<C>(acc, aff_cneg_lazy<C>(q, ent & 1));
+                }
+                acc = nxt;
+            }
             ent = ent_n;
             p = p_n;
         }
