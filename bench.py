@@ -204,6 +204,23 @@ def cpu_quota():
         return os.cpu_count() or 1
 
 
+def mem_limit_bytes():
+    """host memory this process tree may use: the cgroup's memory.max when there is one, else MemAvailable"""
+    try:
+        v = open("/sys/fs/cgroup/memory.max").read().strip()
+        if v != "max":
+            return int(v)
+    except Exception:
+        pass
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) * 1024
+    except Exception:
+        pass
+    return 64 << 30
+
+
 def pmc_traffic(keys, applicable, fname, field="largest"):
     """HBM bytes from the committed rocprofv3 PMC passes (profiles/<fname>, made by tools/pmc_summary.py from FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same workload).  FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950
@@ -988,8 +1005,8 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="host threads running the TranscriptRng head of prove() (0 = 6/16 of this rank's share of the CPU quota)")
     ap.add_argument("--build-threads", type=int, default=0, help="host threads constructing statements (Prover::new + commit + gadget) (0 = half of this rank's share of the CPU quota)")
     ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
-    ap.add_argument("--window", type=int, default=96, help="statements alive at once in the prove pipeline (built, waiting for or in the TranscriptRng stage, "
-                    "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s and 64 at ~21")
+    ap.add_argument("--window", type=int, default=0, help="statements alive at once in the prove pipeline (built, waiting for or in the TranscriptRng stage, "
+                    "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s and 64 at ~21.  0 = 96, or fewer when a quarter of this rank's share of the host memory limit holds fewer")
     ap.add_argument("--fold-tables", type=int, default=2, help="prove workload: fixed-base tables of the generators for the first fold rounds (0 = off, 1 = the first round, "
                     "2 = the first two rounds: tables over 3N/4 bases)")
     ap.add_argument("--msm-tables", type=int, default=1, help="prove workload: fixed-base rows of the generators for the MSMs over the tables themselves (0 = off)")
@@ -1015,6 +1032,9 @@ def main():
     share = max(1.0, cpu_quota() / max(world, 1))
     if args.host_threads <= 0:
         args.host_threads = max(1, int(round(share * 6 / 16)))
+    if args.window <= 0:
+        per_stmt = 0.35e9 * max(1.0, (1 << args.logn) / float(1 << 20))
+        args.window = int(max(16, min(96, (mem_limit_bytes() * 0.25 / max(world, 1)) / per_stmt)))
     if args.build_threads <= 0:
         args.build_threads = max(2, int(round(share * 8 / 16)))
     res = {"msm": run_msm, "prove": run_prove, "verify": run_verify, "headline": run_headline, "shuffle-sweep": run_shuffle_sweep}[args.workload](args, rank, world, local)
