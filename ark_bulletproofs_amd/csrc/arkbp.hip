@@ -586,6 +586,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         if (n >= ctx->tune_msm_bin_min && wbn > 0 && !no_bins) {
             u32 nbin = 1, lg = 0;
             while ((size_t)nbin * 8192 < n && nbin < (u32)pl.NB) { nbin <<= 1; lg++; }
+            // bins of up to 12 K entries (43 KB of LDS in the bin sort) where that keeps the MSM inside the fixed-shape pipeline's bin
+            // limit: 2^20 < n <= 1.5 * 2^20, e.g. the 1.25 M-term MSM of a 4096-proof batch verification
+            if ((size_t)wbn * nbin + 1 > MSM_FS_MAXBINS && nbin >= 2 && (size_t)(nbin / 2) * 12288 >= n && (size_t)wbn * (nbin / 2) + 1 <= MSM_FS_MAXBINS) { nbin >>= 1; lg--; }
             int LB = pl.c - 1 - (int)lg;
             while (LB > 11) { nbin <<= 1; LB--; }
             const double mu = (double)n / nbin;
