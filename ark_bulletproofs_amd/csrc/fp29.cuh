@@ -27,11 +27,9 @@
 #include <hip/hip_runtime.h>
 #define ARKBP_HD __host__ __device__ __forceinline__
 #define ARKBP_DEV_NOINLINE __device__ __noinline__
-#define ARKBP_HD_NOINLINE __host__ __device__ __noinline__
 #else
 #define ARKBP_HD inline
 #define ARKBP_DEV_NOINLINE inline
-#define ARKBP_HD_NOINLINE inline
 #endif
 #include "arkbp_params.h"
 
