@@ -1,6 +1,8 @@
 // libarkbp_hip.so — context, workspaces, host orchestration and the C ABI (include/arkbp.h).
 // There is no CPU fallback: without a HIP device every compute entry point returns BP_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <sys/prctl.h>
+#include <time.h>
 #include <rccl/rccl.h>   // types only: the entry points are bound with dlsym (rccl_api)
 #include <dlfcn.h>
 #include <mutex>
@@ -213,6 +215,8 @@ struct bp_ctx {
     size_t tune_cyclic_min = (size_t)1 << 14;   // BP_TUNE_CYCLIC_MIN: padded size from which a sharded prover partitions the IPA
     size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
     size_t tune_host_threads = 0;                  // BP_TUNE_HOST_THREADS: size of this ctx's host pool (0 = host_pool_threads())
+    hipEvent_t sync_ev_aux = nullptr;              // event of ctx_aux_stream_wait
+    bool tune_wait_sleep = false;                  // BP_TUNE_WAIT_SLEEP: host waits poll and sleep instead of busy-waiting (see event_wait)
     bool msm_latency_first = false;                // set by the bp_msm* entry points for the duration of the call (see msm_use_quad)
     size_t tune_msm_chunk_cap = 0;                 // BP_TUNE_MSM_CHUNK_CAP: entries per level-1 chunk of the fixed-shape MSM pipeline (0 = fs_chunk_cap's choice)
     size_t tune_fold_quad_max = 0;                 // BP_TUNE_FOLD_QUAD_MAX: fold rounds with at most this many output points run four lanes per point (0 = never)
@@ -237,19 +241,47 @@ static int get_event(bp_ctx* c, hipEvent_t* e) {
     HIPCHK(hipEventCreate(e));
     return BP_OK;
 }
-// Waits for the ctx's stream.  hipStreamSynchronize spins on the host; with a dozen proofs in flight that is a dozen cores doing
-// nothing — on a box whose CPU time is rationed (the GPU boxes here grant 16 CPUs per GPU through a cgroup quota) the spinning
-// starves the threads that have real work (TranscriptRng, statement construction, transcript replays).  Waiting on an event created
-// with hipEventBlockingSync sleeps instead.  ARKBP_SYNC=spin restores the spinning wait (A/B; also measured for the single-MSM
-// callers, where it gains nothing: 0.485 / 0.491 ms spinning against 0.481 / 0.484 sleeping at 2^16 terms).
-static hipError_t ctx_stream_wait(bp_ctx* c) {
-    static const bool spin = getenv("ARKBP_SYNC") && !strcmp(getenv("ARKBP_SYNC"), "spin");
-    if (spin) return hipStreamSynchronize(c->stream);
-    if (!c->sync_ev) { hipError_t e = hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming); if (e != hipSuccess) return e; }
-    hipError_t e = hipEventRecord(c->sync_ev, c->stream);
-    if (e != hipSuccess) return e;
-    return hipEventSynchronize(c->sync_ev);
+// Host waits.  hipStreamSynchronize AND hipEventSynchronize busy-wait on this stack — also for events created with
+// hipEventBlockingSync: measured 1.00 core of process CPU per waiting thread (tools/wait_cpu.py; a 2^22-term MSM: 117.3 ms of wall,
+// 117.3 ms of CPU).  With eight proofs in flight that was seven cores of a 16-CPU quota doing nothing, and the quota was what bounded
+// the prover pipeline (bench.py config.host_cpu_in_timed_region: 12.5 cores used, the cgroup throttled in a third of its periods).
+// BP_TUNE_WAIT_SLEEP = 1 makes a ctx's waits poll the event and sleep ~50 us in between: one 2^20 proof then costs 20 ms of host CPU
+// instead of 68 (wall 67.7 -> 68.9 ms) and the pipeline's throughput is unchanged at 7.9 instead of 12.5 cores — the setting for a
+// prover service.  Batch verification waits far more often per millisecond of GPU work and lost 10 % with it, so the default stays
+// the busy wait (ARKBP_SYNC=sleep / =spin force either everywhere); the bp_msm* entry points always busy-wait.
+static void wait_thread_setup() {
+    static thread_local bool done = false;
+    if (!done) { done = true; (void)prctl(PR_SET_TIMERSLACK, 5000UL, 0, 0, 0); }   // 5 us of timer slack instead of 50: short sleeps stay short
 }
+static int wait_env() {   // -1: per ctx (BP_TUNE_WAIT_SLEEP), 0: busy wait everywhere, 1: sleeping waits everywhere
+    static const int v = !getenv("ARKBP_SYNC") ? -1 : !strcmp(getenv("ARKBP_SYNC"), "sleep") ? 1 : !strcmp(getenv("ARKBP_SYNC"), "spin") ? 0 : -1;
+    return v;
+}
+static bool wait_sleeps(const bp_ctx* c) { const int e = wait_env(); return e >= 0 ? e == 1 : (c && c->tune_wait_sleep); }
+static hipError_t event_wait(const bp_ctx* c, hipEvent_t ev) {
+    if (!wait_sleeps(c)) return hipEventSynchronize(ev);
+    wait_thread_setup();
+    for (int it = 0;; it++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return hipSuccess;
+        if (e != hipErrorNotReady) return e;
+        if (it < 3) continue;                              // (a wait that is over within a few microseconds costs no sleep)
+        struct timespec ts = {0, it < 40 ? 30000L : 60000L};
+        nanosleep(&ts, nullptr);
+    }
+}
+static hipError_t stream_wait(bp_ctx* c, hipStream_t stream, hipEvent_t& ev) {
+    if (!wait_sleeps(c)) return hipStreamSynchronize(stream);
+    if (!ev) { hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
+    hipError_t e = hipEventRecord(ev, stream);
+    if (e != hipSuccess) return e;
+    return event_wait(c, ev);
+}
+static hipError_t ctx_stream_wait(bp_ctx* c) {
+    if (c->msm_latency_first) return hipStreamSynchronize(c->stream);
+    return stream_wait(c, c->stream, c->sync_ev);
+}
+static hipError_t ctx_aux_stream_wait(bp_ctx* c) { return stream_wait(c, c->aux_stream, c->sync_ev_aux); }
 // all-gather of `bytes` host bytes per rank -> recv (world x bytes, rank order): ncclAllGather on the ctx's stream between a pinned
 // H2D and a pinned D2H copy; the stream order puts it behind the kernels already enqueued
 static int ctx_native_allgather(bp_ctx* c, const void* send, size_t bytes, void* recv) {
@@ -2253,6 +2285,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     collect_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
+    if (c->sync_ev_aux) (void)hipEventDestroy(c->sync_ev_aux);
     DevBuf* bufs[] = {&c->canon, &c->hist, &c->lvl_off, &c->totals, &c->cursor, &c->entries, &c->slots, &c->bin_cur, &c->boff, &c->lvA, &c->lvB, &c->Tbuf, &c->io_pts, &c->io_scal, &c->io_out,
                       &c->ipa_G, &c->ipa_H, &c->ipa_a, &c->ipa_b, &c->ipa_Gf, &c->ipa_Hf, &c->ipa_sL, &c->ipa_sR, &c->ipa_part, &c->ipa_Q, &c->ipa_jac, &c->ipa_pref, &c->ipa_cG, &c->ipa_cH,
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
@@ -2340,6 +2373,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
         case BP_TUNE_MSM_WSUM_MIN: c->tune_msm_wsum_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_GLV_MIN: c->tune_msm_glv_min = (size_t)value; return BP_OK;
         case BP_TUNE_FOLD_QUAD_MAX: c->tune_fold_quad_max = (size_t)value; return BP_OK;
+        case BP_TUNE_WAIT_SLEEP: c->tune_wait_sleep = value != 0; return BP_OK;
         case BP_TUNE_MSM_CHUNK_CAP: if (value && (value < 8 || value > 64)) return BP_E_ARG; c->tune_msm_chunk_cap = (size_t)value; return BP_OK;
     }
     return BP_E_ARG;

@@ -204,6 +204,25 @@ def cpu_quota():
         return os.cpu_count() or 1
 
 
+def cgroup_cpu_stat():
+    """(usage_usec, nr_periods, nr_throttled, throttled_usec) of this cgroup, or None"""
+    try:
+        d = dict(ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))
+        return tuple(int(d.get(k, 0)) for k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec"))
+    except Exception:
+        return None
+
+
+def cgroup_cpu_delta(before, wall_s):
+    """host CPU actually consumed over a timed region and how often the cgroup's quota stopped the process tree in it"""
+    after = cgroup_cpu_stat()
+    if not before or not after or wall_s <= 0:
+        return None
+    per = max(1, after[1] - before[1])
+    return {"avg_cores_used": (after[0] - before[0]) / 1e6 / wall_s, "quota_cores": cpu_quota(), "periods": after[1] - before[1],
+            "periods_throttled_frac": (after[2] - before[2]) / per, "throttled_s": (after[3] - before[3]) / 1e6}
+
+
 def mem_limit_bytes():
     """host memory this process tree may use: the cgroup's memory.max when there is one, else MemAvailable"""
     try:
@@ -488,6 +507,8 @@ def run_prove(args, rank, world, local):
     if getattr(args, "freeze_len", 0):
         for e in engs:
             e.set_tuning(2, args.freeze_len)
+    for e in engs:
+        e.set_tuning(10, 1)      # BP_TUNE_WAIT_SLEEP: the GPU driver threads sleep while they wait (HIP's waits burn a core each)
     if window_sharded:
         # north_star / cfg5 partition: all ranks prove the SAME statements; every MSM inside prove() accumulates the rank's Pippenger
         # windows and the partial points are summed over RCCL (strong scaling of one proof at a time: one proof in flight, because
@@ -519,9 +540,11 @@ def run_prove(args, rank, world, local):
     flat = [None] * nproofs
     pipe.keep_info = {0, nproofs - 1}
     barrier(world)
+    cpu0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
     pipe.run(0, nproofs, flat)                   # K steps x `batch` proofs, statement construction included
     barrier(world)
+    host_cpu = cgroup_cpu_delta(cpu0, time.perf_counter() - t0)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     # The proofs that were timed are checked (after the timed region): the first and the last of the run go through the GPU verifier
     # — Verifier::verify, src/r1cs/verifier.rs:549-600 — and a copy with one flipped bit of t_x must be rejected; the run fails otherwise.
@@ -579,7 +602,7 @@ def run_prove(args, rank, world, local):
                    "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
                    "verified": verified, "verified_note": "timed proofs 0 and %d verified on the GPU after the timed region, a tampered copy of each rejected" % (nproofs - 1),
                    "table_entries_failing_check": tables_bad, "tables_check_s": t_chk if tables_bad is not None else None, "collectives": coll_info,
-                   "pipeline_thread_seconds_per_wall_second": pipe_util, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
+                   "pipeline_thread_seconds_per_wall_second": pipe_util, "host_cpu_in_timed_region": host_cpu, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
     if fold_n:
