@@ -73,6 +73,10 @@ def kernel_entry(name, ms, launches, alg_bytes, traffic, products, note=""):
     return e
 CURVES = ["secq256k1", "zorro"]
 
+# Eight HIP streams (the proofs in flight) share FOUR hardware queues by default: at most four kernels run at once and the GPU idles a
+# quarter of the time (profiles/r03_gpu_busy_prove.txt).  Sixteen queues: prove +6 %, batch verification unchanged within its noise
+# (eight queues cost it ~7 %).  Read by the HIP runtime when it initialises, so it is set before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 COLL_DEVICE = "cuda"   # where the collectives' tensors live ("cuda" over RCCL; None = CPU tensors over gloo, rehearsal only)
 
 
