@@ -216,7 +216,7 @@ struct bp_ctx {
     size_t tune_msm_fixed_min = (size_t)1 << 20;   // BP_TUNE_MSM_FIXED_MIN: terms from which MSMs over the generator tables use the fixed-base rows
     size_t tune_host_threads = 0;                  // BP_TUNE_HOST_THREADS: size of this ctx's host pool (0 = host_pool_threads())
     hipEvent_t sync_ev_aux = nullptr;              // event of ctx_aux_stream_wait
-    bool tune_wait_sleep = false;                  // BP_TUNE_WAIT_SLEEP: host waits poll and sleep instead of busy-waiting (see event_wait)
+    unsigned tune_wait_sleep = 0;                  // BP_TUNE_WAIT_SLEEP: host waits poll and sleep this many microseconds in between instead of busy-waiting (see event_wait)
     bool msm_latency_first = false;                // set by the bp_msm* entry points for the duration of the call (see msm_use_quad)
     size_t tune_msm_chunk_cap = 0;                 // BP_TUNE_MSM_CHUNK_CAP: entries per level-1 chunk of the fixed-shape MSM pipeline (0 = fs_chunk_cap's choice)
     size_t tune_fold_quad_max = 0;                 // BP_TUNE_FOLD_QUAD_MAX: fold rounds with at most this many output points run four lanes per point (0 = never)
@@ -251,13 +251,14 @@ static int get_event(bp_ctx* c, hipEvent_t* e) {
 // the busy wait (ARKBP_SYNC=sleep / =spin force either everywhere); the bp_msm* entry points always busy-wait.
 static void wait_thread_setup() {
     static thread_local bool done = false;
-    if (!done) { done = true; (void)prctl(PR_SET_TIMERSLACK, 5000UL, 0, 0, 0); }   // 5 us of timer slack instead of 50: short sleeps stay short
+    if (!done) { done = true; (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0); }   // 2 us of timer slack instead of 50: short sleeps stay short
 }
 static int wait_env() {   // -1: per ctx (BP_TUNE_WAIT_SLEEP), 0: busy wait everywhere, 1: sleeping waits everywhere
     static const int v = !getenv("ARKBP_SYNC") ? -1 : !strcmp(getenv("ARKBP_SYNC"), "sleep") ? 1 : !strcmp(getenv("ARKBP_SYNC"), "spin") ? 0 : -1;
     return v;
 }
-static bool wait_sleeps(const bp_ctx* c) { const int e = wait_env(); return e >= 0 ? e == 1 : (c && c->tune_wait_sleep); }
+static unsigned wait_sleep_us(const bp_ctx* c) { const int e = wait_env(); return e == 0 ? 0u : (c && c->tune_wait_sleep) ? c->tune_wait_sleep : e == 1 ? 30u : 0u; }
+static bool wait_sleeps(const bp_ctx* c) { return wait_sleep_us(c) != 0; }
 static hipError_t event_wait(const bp_ctx* c, hipEvent_t ev) {
     if (!wait_sleeps(c)) return hipEventSynchronize(ev);
     wait_thread_setup();
@@ -266,7 +267,8 @@ static hipError_t event_wait(const bp_ctx* c, hipEvent_t ev) {
         if (e == hipSuccess) return hipSuccess;
         if (e != hipErrorNotReady) return e;
         if (it < 3) continue;                              // (a wait that is over within a few microseconds costs no sleep)
-        struct timespec ts = {0, it < 40 ? 30000L : 60000L};
+        const long ns = (long)wait_sleep_us(c) * 1000L;
+        struct timespec ts = {0, it < 40 ? ns : 2 * ns};
         nanosleep(&ts, nullptr);
     }
 }
@@ -2373,7 +2375,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
         case BP_TUNE_MSM_WSUM_MIN: c->tune_msm_wsum_min = (size_t)value; return BP_OK;
         case BP_TUNE_MSM_GLV_MIN: c->tune_msm_glv_min = (size_t)value; return BP_OK;
         case BP_TUNE_FOLD_QUAD_MAX: c->tune_fold_quad_max = (size_t)value; return BP_OK;
-        case BP_TUNE_WAIT_SLEEP: c->tune_wait_sleep = value != 0; return BP_OK;
+        case BP_TUNE_WAIT_SLEEP: if (value > 1000) return BP_E_ARG; c->tune_wait_sleep = value == 1 ? 30u : (unsigned)value; return BP_OK;
         case BP_TUNE_MSM_CHUNK_CAP: if (value && (value < 8 || value > 64)) return BP_E_ARG; c->tune_msm_chunk_cap = (size_t)value; return BP_OK;
     }
     return BP_E_ARG;

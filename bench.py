@@ -512,7 +512,7 @@ def run_prove(args, rank, world, local):
         for e in engs:
             e.set_tuning(2, args.freeze_len)
     for e in engs:
-        e.set_tuning(10, 1)      # BP_TUNE_WAIT_SLEEP: the GPU driver threads sleep while they wait (HIP's waits burn a core each)
+        e.set_tuning(10, 30)     # BP_TUNE_WAIT_SLEEP: the GPU driver threads sleep 30 us between polls (HIP's waits burn a core each)
     if window_sharded:
         # north_star / cfg5 partition: all ranks prove the SAME statements; every MSM inside prove() accumulates the rank's Pippenger
         # windows and the partial points are summed over RCCL (strong scaling of one proof at a time: one proof in flight, because
@@ -760,10 +760,14 @@ def run_verify(args, rank, world, local):
         per_pool = min(32, max(4, int(round(cpu_quota() / world * 1.5 / nfl))))   # (the ranks of a node share its quota)
         for e in engs:
             e.set_tuning(6, per_pool)   # BP_TUNE_HOST_THREADS
+    if getattr(args, "verify_wait_us", 0):
+        for e in engs:
+            e.set_tuning(10, args.verify_wait_us)   # BP_TUNE_WAIT_SLEEP
     for _ in range(args.warmup):
         for e in engs:
             e.batch_verify(inst, seed, alpha_skip=lo)
     barrier(world)
+    cpu0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
     tms = np.zeros(5)
     ok = True
@@ -793,6 +797,7 @@ def run_verify(args, rank, world, local):
     ok = ok and len(tml) == args.steps
     tms = np.sum(np.array(tml), axis=0)
     barrier(world)
+    host_cpu = cgroup_cpu_delta(cpu0, time.perf_counter() - t0)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     assert ok, "batch verification of valid proofs failed"
     for e in engs[1:]:
@@ -817,7 +822,7 @@ def run_verify(args, rank, world, local):
                                ("cfg4: batch_verify of %d R1CS proofs per GPU, 2^14 constraints each (256 x 64-bit range proofs, m=256), %s"
                                 % (args.proofs, CURVES[args.curve])),
                    "proofs_per_gpu": args.proofs, "distinct_proofs": len(distinct), "constraints_per_proof": N, "parallelism": "proof-sharded x%d" % world,
-                   "batches_in_flight": nfl,
+                   "batches_in_flight": nfl, "host_cpu_in_timed_region": host_cpu,
                    "stage_ms_per_step": {"whole_call": tms[0] / args.steps * 1e3, "host_replay_overlapped_with_gpu": tms[1] / args.steps * 1e3,
                                          "gpu_drain_and_tail_scaling": tms[2] / args.steps * 1e3, "final_msm": tms[3] / args.steps * 1e3,
                                          "decode": tms[4] / args.steps * 1e3}},
@@ -1041,6 +1046,7 @@ def main():
     ap.add_argument("--cfg5-logn", type=int, default=22, help="headline with --gpus N > 1: size of the window-sharded proofs of the cfg5 leg (0 = skip the leg)")
     ap.add_argument("--cfg5-steps", type=int, default=2, help="steps (of 8 proofs) of the cfg5 leg")
     ap.add_argument("--cfg5-timeout", type=int, default=600, help="seconds after which the cfg5 leg is given up and the headline line printed without it")
+    ap.add_argument("--verify-wait-us", type=int, default=0, help="verify workload: BP_TUNE_WAIT_SLEEP of the batch ctxs in microseconds (0 = HIP's busy wait)")
     ap.add_argument("--freeze-len", type=int, default=0, help="prove workload: BP_TUNE_IPA_FREEZE_LEN of every ctx (0 = the library's default)")
     ap.add_argument("--tables-off-steps", type=int, default=4, help="prove workload: timed steps of the same pipeline with the precomputed tables released (0 = skip)")
     ap.add_argument("--fold-table-bits", type=int, default=0, help="window width of those tables (0 = the widest that fits in 3/4 of the free HBM)")

@@ -410,9 +410,10 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
                                      point (quad-cooperative group arithmetic): shorter rounds, more arithmetic; default 0 = never (a prover that keeps the GPU
                                      full gains nothing); a latency-bound single prover sets 2^14 */
 #define BP_TUNE_MSM_GLV_MIN 7     /* terms from which a variable-base MSM on secq256k1 splits its scalars with the endomorphism (default 256; a huge value turns it off) */
-#define BP_TUNE_WAIT_SLEEP 10     /* 1: this ctx's host waits poll the GPU event and sleep ~50 us in between instead of busy-waiting (what the HIP
-                                     synchronisation calls do on this stack): a third of the host CPU per proof for ~2 % of latency; the setting for a
-                                     prover that keeps several proofs in flight.  Default 0 (batch verification waits often and loses 10 % with it) */
+#define BP_TUNE_WAIT_SLEEP 10     /* microseconds this ctx's host waits sleep between polls of the GPU event, instead of busy-waiting (what the HIP
+                                     synchronisation calls do on this stack: one core per waiting thread); 0 = busy wait (default), 1 = 30 us, at most 1000.
+                                     30 us: a third of the host CPU per proof for ~2 % of latency, for a prover that keeps several proofs in flight;
+                                     batch verification waits often and shortly: 10 us */
 #define BP_TUNE_MSM_CHUNK_CAP 9   /* entries per first-level chunk of the mid-size (fixed-shape) MSM pipeline: 8 .. 64; 0 = default (16 for callers that keep
                                      the GPU full; fitted per MSM to whole waves per SIMD for the bp_msm* entry points).  Results never depend on it */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
