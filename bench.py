@@ -227,6 +227,21 @@ def cgroup_cpu_delta(before, wall_s):
             "periods_throttled_frac": (after[2] - before[2]) / per, "throttled_s": (after[3] - before[3]) / 1e6}
 
 
+def host_cpu_info():
+    """CPU model of the host and whether the AVX-512 lockstep paths of the library (TranscriptRng x8, commitment appends x8) apply"""
+    model, flags = None, ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if model is None and ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+            if ln.startswith("flags"):
+                flags = ln
+                break
+    except Exception:
+        pass
+    return {"model": model, "avx512f": " avx512f" in flags}
+
+
 def mem_limit_bytes():
     """host memory this process tree may use: the cgroup's memory.max when there is one, else MemAvailable"""
     try:
@@ -606,7 +621,7 @@ def run_prove(args, rank, world, local):
                    "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
                    "verified": verified, "verified_note": "timed proofs 0 and %d verified on the GPU after the timed region, a tampered copy of each rejected" % (nproofs - 1),
                    "table_entries_failing_check": tables_bad, "tables_check_s": t_chk if tables_bad is not None else None, "collectives": coll_info,
-                   "pipeline_thread_seconds_per_wall_second": pipe_util, "host_cpu_in_timed_region": host_cpu, "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
+                   "pipeline_thread_seconds_per_wall_second": pipe_util, "host_cpu_in_timed_region": host_cpu, "host_cpu": host_cpu_info(), "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
     if fold_n:
