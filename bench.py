@@ -1049,11 +1049,11 @@ def main():
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
     ap.add_argument("--cpu-verify-proofs", type=int, default=256, help="CPU baseline sample of the verify workload (about 10 s)")
     ap.add_argument("--batch", type=int, default=16, help="independent proofs per step per GPU (prove workload)")
-    ap.add_argument("--host-threads", type=int, default=0, help="host threads running the TranscriptRng head of prove() (0 = 6/16 of this rank's share of the CPU quota)")
-    ap.add_argument("--build-threads", type=int, default=0, help="host threads constructing statements (Prover::new + commit + gadget) (0 = half of this rank's share of the CPU quota)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads running the TranscriptRng head of prove() (0 = half of this rank's share of the CPU quota)")
+    ap.add_argument("--build-threads", type=int, default=0, help="host threads constructing statements (Prover::new + commit + gadget) (0 = 6/16 of this rank's share of the CPU quota)")
     ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (prove workload)")
     ap.add_argument("--window", type=int, default=0, help="statements alive at once in the prove pipeline (built, waiting for or in the TranscriptRng stage, "
-                    "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s and 64 at ~21.  0 = 96, or fewer when a quarter of this rank's share of the host memory limit holds fewer")
+                    "on the GPU); ~0.3 GB of host memory each at 2^20.  Little's law: a statement spends ~3 s in the pipeline, so 32 caps the rate at ~11 proofs/s and 64 at ~21.  0 = 128, or fewer when a quarter of this rank's share of the host memory limit holds fewer")
     ap.add_argument("--fold-tables", type=int, default=2, help="prove workload: fixed-base tables of the generators for the first fold rounds (0 = off, 1 = the first round, "
                     "2 = the first two rounds: tables over 3N/4 bases)")
     ap.add_argument("--msm-tables", type=int, default=1, help="prove workload: fixed-base rows of the generators for the MSMs over the tables themselves (0 = off)")
@@ -1075,16 +1075,17 @@ def main():
         sys.exit(spawn_ranks(args.gpus))        # this process has not touched the GPU
     rank, world, local = dist_setup(args.gpus)
     # host thread counts of the prove pipeline from this rank's share of the CPUs (the ranks of a node share the cgroup's quota;
-    # measured on a 16-CPU share: 6 + 8 beside the 8 GPU driver threads; 5 + 8 left the GPU threads waiting for statements once the
-    # kernels of a proof had come down to ~42 ms)
+    # on a 16-CPU share: 8 TranscriptRng + 6 statement builders beside the 8 GPU driver threads, which sleep while they wait
+    # (BP_TUNE_WAIT_SLEEP).  Six TranscriptRng threads feed a 26 M constraints/s GPU on the usual boxes — the seventh and eighth
+    # wait there and cost nothing — but on the occasional box whose cores run that stage 3x slower they are the difference.)
     share = max(1.0, cpu_quota() / max(world, 1))
     if args.host_threads <= 0:
-        args.host_threads = max(1, int(round(share * 6 / 16)))
+        args.host_threads = max(1, int(round(share * 8 / 16)))
     if args.window <= 0:
         per_stmt = 0.35e9 * max(1.0, (1 << args.logn) / float(1 << 20))
-        args.window = int(max(16, min(96, (mem_limit_bytes() * 0.25 / max(world, 1)) / per_stmt)))
+        args.window = int(max(16, min(128, (mem_limit_bytes() * 0.25 / max(world, 1)) / per_stmt)))
     if args.build_threads <= 0:
-        args.build_threads = max(2, int(round(share * 8 / 16)))
+        args.build_threads = max(2, int(round(share * 6 / 16)))
     res = {"msm": run_msm, "prove": run_prove, "verify": run_verify, "headline": run_headline, "shuffle-sweep": run_shuffle_sweep}[args.workload](args, rank, world, local)
     if rank == 0:
         print(json.dumps(res), flush=True)
