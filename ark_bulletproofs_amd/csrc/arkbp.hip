@@ -365,10 +365,11 @@ static MsmPlan msm_plan(size_t n, int bits) {
 // caller waits for the one result: the bp_msm* entry points.  ARKBP_MSM_LATENCY=1 / =0 forces them on / off everywhere (A/B).
 static int msm_latency_env() { static const int v = getenv("ARKBP_MSM_LATENCY") ? atoi(getenv("ARKBP_MSM_LATENCY")) : -1; return v; }
 static bool msm_use_quad(const bp_ctx* ctx) { const int e = msm_latency_env(); return e >= 0 ? e != 0 : ctx->msm_latency_first; }
+static bool msm_quad_trees(const bp_ctx* ctx) { static const bool force = getenv("ARKBP_MSM_QUAD_TREES") != nullptr; return force || msm_use_quad(ctx); }   // (experiment: the quad trees without the GLV split)
 // (direct launches in both branches: a kernel template named only inside a conditional expression is not emitted for the device)
-#define MSM_LAUNCH_REDUCE_FS(red_g, grid, ...) do { if (msm_use_quad(ctx) && (red_g) == 4u) hipLaunchKernelGGL((k_msm_reduce_fs<C, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
+#define MSM_LAUNCH_REDUCE_FS(red_g, grid, ...) do { if (msm_quad_trees(ctx) && (red_g) == 4u) hipLaunchKernelGGL((k_msm_reduce_fs<C, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
                                                     else hipLaunchKernelGGL((k_msm_reduce_fs<C, false>), grid, dim3(256), 0, st, __VA_ARGS__); } while (0)
-#define MSM_LAUNCH_MARGINALS_FS(grid, ...) do { if (msm_use_quad(ctx)) hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
+#define MSM_LAUNCH_MARGINALS_FS(grid, ...) do { if (msm_quad_trees(ctx)) hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, true>), grid, dim3(256), 0, st, __VA_ARGS__); \
                                                 else hipLaunchKernelGGL((k_msm_marginals_fs<C, 256, false>), grid, dim3(256), 0, st, __VA_ARGS__); } while (0)
 // Entries per level-1 chunk of the fixed-shape pipeline.  Throughput callers keep 16.  For a caller waiting on ONE mid-size MSM the
 // accumulate is a single round of workgroups whose duration is (entries per lane) x (latency of a mixed addition at the fill of
