@@ -85,7 +85,23 @@ template <class P> struct Fld {
     static inline F4 sqr(const F4& a) { return mul(a, a); }
     static inline F4 from_u64(u64 x) { F4 a = {{x, 0, 0, 0}}, r2 = {{P::R2_64[0], P::R2_64[1], P::R2_64[2], P::R2_64[3]}}; return mul(a, r2); }
     static inline F4 from_canon(const u64 c[4]) { F4 a; memcpy(a.v, c, 32); F4 r2 = {{P::R2_64[0], P::R2_64[1], P::R2_64[2], P::R2_64[3]}}; return mul(a, r2); }
-    static inline void to_canon(u64 c[4], const F4& a) { F4 o = {{1, 0, 0, 0}}; F4 r = mul(a, o); memcpy(c, r.v, 32); }
+    // Montgomery form -> canonical integer: the reduction alone (a * 1 has no product to form): 20 multiplications instead of 36.
+    // Serialising a proof's 256 commitments for the transcript is 512 of these (a fifth of the verifier's host time per proof).
+    static inline void to_canon(u64 c[4], const F4& a) {
+        u64 t0 = a.v[0], t1 = a.v[1], t2 = a.v[2], t3 = a.v[3];
+#pragma GCC unroll 4
+        for (int i = 0; i < 4; i++) {
+            const u64 m = t0 * P::NINV64;
+            u128 cc = (u128)m * P::P64[0] + t0; cc >>= 64;
+            cc += (u128)m * P::P64[1] + t1; t0 = (u64)cc; cc >>= 64;
+            cc += (u128)m * P::P64[2] + t2; t1 = (u64)cc; cc >>= 64;
+            cc += (u128)m * P::P64[3] + t3; t2 = (u64)cc; cc >>= 64;
+            t3 = (u64)cc;
+        }
+        u64 r[4] = {t0, t1, t2, t3};
+        if (geq_p(r)) sub_p(r);   // (not reached for a < p: (a + M p) / 2^256 < p)
+        memcpy(c, r, 32);
+    }
     static inline F4 pow(const F4& a, const u64 e[4]) {   // fixed 4-bit windows: 256 squarings + <= 64 products + 14 for the table
         F4 tab[16];
         tab[0] = one(); tab[1] = a;
