@@ -308,6 +308,43 @@ struct StrobeX8 {
         absorb_same(hdr, 2);
         if ((flags & (Strobe::fC | Strobe::fK)) && pos != 0) runf();
     }
+    // the states of eight ordinary transcripts that went through the same operations so far (false when their positions differ)
+    bool gather(const Strobe* const in[8]) {
+        for (int j = 1; j < 8; j++) if (in[j]->pos != in[0]->pos || in[j]->pos_begin != in[0]->pos_begin || in[j]->cur != in[0]->cur) return false;
+        for (int i = 0; i < 25; i++) for (int j = 0; j < 8; j++) lanes[i][j] = in[j]->st.w[i];
+        pos = in[0]->pos; pos_begin = in[0]->pos_begin; cur = in[0]->cur;
+        return true;
+    }
+    __attribute__((target("avx512f"))) void squeeze_each(u8* const d[8], size_t n) {   // Strobe::squeeze on all eight: reads and zeroes
+        size_t i = 0;
+        while (i < n) {
+            if ((pos & 7) == 0 && n - i >= 8 && pos + 8 <= Strobe::RATE) {
+                u64* w = lanes[pos >> 3];
+                for (int j = 0; j < 8; j++) { memcpy(d[j] + i, &w[j], 8); w[j] = 0; }
+                i += 8; pos = (u8)(pos + 8);
+            } else {
+                const unsigned sh = 8 * (pos & 7);
+                u64* w = lanes[pos >> 3];
+                for (int j = 0; j < 8; j++) { d[j][i] = (u8)(w[j] >> sh); w[j] &= ~((u64)0xff << sh); }
+                i++; pos++;
+            }
+            if (pos == Strobe::RATE) runf();
+        }
+    }
+    // Transcript::append_message(label, m, n) with the same message on all eight
+    __attribute__((target("avx512f"))) void append_message_same(const char* label, const u8* m, size_t n) {
+        const u32 len = (u32)n;
+        begin(Strobe::fM | Strobe::fA, false); absorb_same((const u8*)label, strlen(label));
+        begin(Strobe::fM | Strobe::fA, true); absorb_same((const u8*)&len, 4);
+        begin(Strobe::fA, false); absorb_same(m, n);
+    }
+    // Transcript::challenge_bytes(label, d_j, n) on all eight
+    __attribute__((target("avx512f"))) void challenge_bytes_each(const char* label, u8* const d[8], size_t n) {
+        const u32 len = (u32)n;
+        begin(Strobe::fM | Strobe::fA, false); absorb_same((const u8*)label, strlen(label));
+        begin(Strobe::fM | Strobe::fA, true); absorb_same((const u8*)&len, 4);
+        begin(Strobe::fI | Strobe::fA | Strobe::fC, false); squeeze_each(d, n);
+    }
     // Transcript::append_message(label, m_j, n) on all eight
     __attribute__((target("avx512f"))) void append_message_each(const char* label, const u8* const m[8], size_t n) {
         const u32 len = (u32)n;
