@@ -17,7 +17,7 @@ EXPORTS = [
     "bp_dev_alloc", "bp_dev_free", "bp_dev_upload", "bp_dev_download", "bp_points_import", "bp_points_export",
     "bp_msm", "bp_msm_gens", "bp_msm_dev", "bp_msm_window_count", "bp_msm_dev_windows", "bp_ipa_create", "bp_ipa_begin", "bp_ipa_round_LR", "bp_ipa_round_fold", "bp_ipa_finish", "bp_ipa_export", "bp_ipa_verify", "bp_gens_derive", "bp_gens_upload", "bp_gens_download", "bp_pedersen_gens",
     "bp_host_derive_generators", "bp_transcript_new", "bp_transcript_free", "bp_transcript_append_message", "bp_transcript_challenge_bytes",
-    "bp_transcript_append_point", "bp_transcript_challenge_scalar", "bp_host_sha3_512", "bp_host_points_sum", "bp_debug_rng_draws", "bp_debug_append_points_x8", "bp_r1cs_prove_scenario", "bp_stmt_prover_create", "bp_stmt_free", "bp_stmt_info", "bp_stmt_prove", "bp_stmt_precompute", "bp_stmt_precompute_batch", "bp_gens_share", "bp_r1cs_verification_gh", "bp_r1cs_verify_scenario", "bp_r1cs_batch_verify_scenarios", "bp_ctx_set_profiling", "bp_ctx_kernel_time", "bp_ctx_reset_profiling",
+    "bp_transcript_append_point", "bp_transcript_challenge_scalar", "bp_host_sha3_512", "bp_host_points_sum", "bp_debug_rng_draws", "bp_debug_append_points_x8", "bp_debug_challenge_x8", "bp_r1cs_prove_scenario", "bp_stmt_prover_create", "bp_stmt_free", "bp_stmt_info", "bp_stmt_prove", "bp_stmt_precompute", "bp_stmt_precompute_batch", "bp_gens_share", "bp_r1cs_verification_gh", "bp_r1cs_verify_scenario", "bp_r1cs_batch_verify_scenarios", "bp_ctx_set_profiling", "bp_ctx_kernel_time", "bp_ctx_reset_profiling",
     "bp_debug_decompress", "bp_debug_field_op", "bp_debug_point_op", "bp_debug_glv_decompose", "bp_ctx_set_tuning", "bp_ctx_set_window_shard", "bp_pedersen_commit_batch", "bp_stmt_prover_create_dev",
     # r1cs::ConstraintSystem / Prover / Verifier for the caller's own gadgets
     "bp_prover_new", "bp_verifier_new", "bp_verifier_new_like", "bp_cs_free", "bp_cs_transcript", "bp_cs_metrics", "bp_prover_commit", "bp_verifier_commit",

@@ -2261,6 +2261,26 @@ template <class C> __attribute__((target("avx512f"))) static void dbg_append_poi
 }
 #endif
 
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) static int dbg_challenge_x8(void* const* trs, const char* msg_label, const uint8_t* msg, size_t msg_len, const char* chal_label, size_t nbytes,
+                                                                uint8_t* out) {
+    host::StrobeX8 sx;
+    const host::Strobe* in[8];
+    for (int l = 0; l < 8; l++) in[l] = &((host::Transcript*)trs[l])->s;
+    if (!sx.gather(in)) return BP_E_ARG;
+    sx.append_message_same(msg_label, msg, msg_len);
+    uint8_t buf[8][64];
+    uint8_t* wp[8];
+    for (int l = 0; l < 8; l++) wp[l] = buf[l];
+    sx.challenge_bytes_each(chal_label, wp, nbytes);
+    for (int l = 0; l < 8; l++) memcpy(out + (size_t)l * nbytes, buf[l], nbytes);
+    host::Strobe* outs[8];
+    for (int l = 0; l < 8; l++) outs[l] = &((host::Transcript*)trs[l])->s;
+    sx.scatter(outs, 8);
+    return BP_OK;
+}
+#endif
+
 extern "C" {
 
 int bp_device_count(void) {
@@ -2609,6 +2629,18 @@ int bp_debug_append_points_x8(int curve, void* const* transcripts, int lanes, co
     if (!host::cpu_has_avx512()) return BP_E_ARG;
     if (curve == 0) dbg_append_points_x8<Secq>(transcripts, lanes, label, points_xy, npts); else dbg_append_points_x8<Zorro>(transcripts, lanes, label, points_xy, npts);
     return BP_OK;
+#else
+    return BP_E_ARG;
+#endif
+}
+// test hook of the rest of the lockstep replay (host::StrobeX8::gather / append_message_same / challenge_bytes_each / scatter): the
+// eight transcripts (any states at the same STROBE position) take `msg` under `msg_label` and then give `nbytes` (<= 64) challenge
+// bytes each under `chal_label`: out = [8][nbytes].  Must equal bp_transcript_append_message + challenge bytes lane by lane.
+int bp_debug_challenge_x8(void* const* transcripts, const char* msg_label, const uint8_t* msg, size_t msg_len, const char* chal_label, size_t nbytes, uint8_t* out) {
+    if (!transcripts || !msg_label || !chal_label || !out || nbytes == 0 || nbytes > 64 || (msg_len && !msg)) return BP_E_ARG;
+#if defined(__x86_64__)
+    if (!host::cpu_has_avx512()) return BP_E_ARG;
+    return dbg_challenge_x8(transcripts, msg_label, msg, msg_len, chal_label, nbytes, out);
 #else
     return BP_E_ARG;
 #endif

@@ -365,6 +365,19 @@ def debug_append_points_x8(curve, transcripts, label, points):
     return True
 
 
+def debug_challenge_x8(transcripts, msg_label, msg, chal_label, nbytes):
+    """eight HostTranscripts at the same STROBE position: append `msg` under `msg_label` and draw `nbytes` challenge bytes each under
+    `chal_label`, all in lockstep (AVX-512 Keccak-f x8); returns an (8, nbytes) u8 array, or None if unavailable"""
+    arr = (C.c_void_p * 8)(*[t.h for t in transcripts])
+    out = np.zeros((8, nbytes), dtype=np.uint8)
+    m = np.frombuffer(bytes(msg), dtype=np.uint8).copy() if len(msg) else np.zeros(1, dtype=np.uint8)
+    rc = lib().bp_debug_challenge_x8(arr, bytes(msg_label), ptr(m), C.c_size_t(len(msg)), bytes(chal_label), C.c_size_t(nbytes), ptr(out))
+    if rc == _lib.BP_E_ARG:
+        return None
+    check(rc, "bp_debug_challenge_x8")
+    return out
+
+
 def pedersen_gens(curve):
     B, Bb = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
     check(lib().bp_pedersen_gens(curve, ptr(B), ptr(Bb)), "bp_pedersen_gens")

@@ -207,6 +207,12 @@ int bp_debug_rng_draws(int curve, void* transcript, const uint64_t* witness, siz
  * must all be in the state of transcripts[0]; points_xy = [lane][npts][8].  The result must equal bp_transcript_append_point applied
  * lane by lane.  BP_E_ARG when the host has no AVX-512 (the product then takes the scalar path). */
 int bp_debug_append_points_x8(int curve, void* const* transcripts, int lanes, const char* label, const uint64_t* points_xy, size_t npts);
+/* Test hook of the rest of the lockstep replay (gather / same-message append / challenge / scatter of host::StrobeX8): the EIGHT
+ * transcripts — any contents, but at the same STROBE position — take `msg` under `msg_label`, then give `nbytes` (1..64) challenge bytes
+ * each under `chal_label`; out = [8][nbytes].  Must equal bp_transcript_append_message + bp_transcript_challenge_bytes lane by lane,
+ * and leave the transcripts in the same states.  BP_E_ARG without AVX-512 or when the positions differ. */
+int bp_debug_challenge_x8(void* const* transcripts, const char* msg_label, const uint8_t* msg, size_t msg_len, const char* chal_label, size_t nbytes,
+                          uint8_t* out);
 /* group sum of affine points on the host (the point-reduce after an all-gather of per-GPU partials) */
 int bp_host_points_sum(int curve, const uint64_t* pts_xy, size_t count, uint64_t out_xy[8]);
 

@@ -226,3 +226,29 @@ print(json.dumps(res), flush=True)
         assert len(lines) == 1, out.stdout
         d = json.loads(lines[0])
         assert d["value"] == 1.0 and d["verify"]["value"] == 2.0 and "error" in d["cfg5"], d
+
+
+@pytest.mark.parametrize("prefix,msg_len,nbytes", [(0, 8, 32), (3, 65, 32), (150, 11, 32), (165, 6, 64), (77, 0, 1), (140, 40, 33)])
+def test_product_lockstep_challenges_equal_scalar_challenges(E, prefix, msg_len, nbytes):
+    """the batch verifier runs the whole Fiat-Shamir replay of eight same-shaped proofs in lockstep (host::StrobeX8: gather, appends
+    with the same or with per-lane messages, challenge_bytes_each, scatter): challenges and final states must equal eight ordinary
+    transcripts', for any STROBE position (0 .. 165 of the 166-byte rate) and for challenge lengths that cross 64-bit words and the
+    rate boundary."""
+    a = [E.HostTranscript(b"lockstep-challenge") for _ in range(8)]
+    b = [E.HostTranscript(b"lockstep-challenge") for _ in range(8)]
+    for l in range(8):
+        for t in (a[l], b[l]):
+            t.append_message(b"lane", bytes([l]) * 8)                  # different contents, same position
+            if prefix:
+                t.append_message(b"pad", bytes(range(prefix)))
+    msg = bytes((7 * i + 1) % 256 for i in range(msg_len))
+    got = E.debug_challenge_x8(a, b"m", msg, b"y", nbytes)
+    if got is None:
+        pytest.skip("no AVX-512 on this host: the product takes the scalar path")
+    for l in range(8):
+        b[l].append_message(b"m", msg)
+        assert bytes(got[l]) == b[l].challenge_bytes(b"y", nbytes), l
+        a[l].append_message(b"after", b"z" * 170)
+        b[l].append_message(b"after", b"z" * 170)
+        assert a[l].challenge_bytes(b"c", 40) == b[l].challenge_bytes(b"c", 40), l
+    assert len({bytes(got[l]) for l in range(8)}) == 8
