@@ -24,6 +24,9 @@
 #include "host_proto.hpp"
 #include "r1cs.cuh"
 #include "pedersen.cuh"
+#include "vfe.hpp"
+#include "vfe_sched.hpp"
+static_assert(arkbp::vfe::PB_WORDS == arkbp::VFY_PB_WORDS, "parameter block layout shared by vfe.hip and r1cs.cuh");
 
 using namespace arkbp;
 using arkbp::host::A4;
@@ -61,9 +64,20 @@ static RcclApi& rccl_api() {
     std::call_once(once, [] {
         void* h = nullptr;
         const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (h) break; }   // the copy the process already mapped
-        if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
-        if (!h) { api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+        // ARKBP_RCCL_LIB names the library to bind instead (tests point it at a path that does not exist to drive the error path)
+        const char* forced = getenv("ARKBP_RCCL_LIB");
+        std::string last_err;
+        auto try_open = [&](const char* n, int flags) {
+            h = dlopen(n, flags);
+            if (!h) { const char* e = dlerror(); if (e) last_err = e; }   // dlerror() clears the message it returns: read it ONCE
+            return h != nullptr;
+        };
+        if (forced) try_open(forced, RTLD_NOW | RTLD_GLOBAL);
+        else {
+            for (const char* n : names) if (try_open(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL)) break;   // the copy the process already mapped
+            if (!h) for (const char* n : names) if (try_open(n, RTLD_NOW | RTLD_GLOBAL)) break;
+        }
+        if (!h) { api.why = std::string("librccl not found: ") + last_err; return; }
         api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
@@ -179,6 +193,13 @@ struct bp_ctx {
     // batch verification: per-proof parameter blocks, chunk partials; cached circuit templates (VTemplate<C>)
     DevBuf v_params, v_gpart, v_hpart, v_alpha, v_tables, v_dec;
     DevBuf p_moff, p_ment, p_mc, p_coefs, p_ztab;   // prover-side constraint index of the statement being proved (k_r1cs_flatten)
+    // verifier front end on the device (vfe.hip; r1cs_host.inc batch_verify_device): raw inputs, serialized items, challenges, scratch
+    DevBuf vfe_in, vfe_msg, vfe_chal, vfe_ws, vfe_small;
+    void* h_vfe = nullptr;                    // pinned staging: [proof bytes | commitments | transcript states | small results]
+    size_t h_vfe_cap = 0;
+    std::map<std::string, std::shared_ptr<void>> vfe_classes;   // (shared recording, m, k, transcript position) -> VfeClassDev<C>
+    bool tune_vfy_device = true;              // BP_TUNE_VFY_DEVICE
+    uint64_t vfe_batches = 0, vfe_fallbacks = 0;                 // batches the device front end completed / handed to the host replay
     void* h_vstage[2] = {nullptr, nullptr};   // pinned staging halves of the batch-verify pipeline
     size_t h_vstage_cap[2] = {0, 0};
     hipEvent_t vstage_ev[2] = {nullptr, nullptr};
@@ -2059,6 +2080,20 @@ static int cs_batch_verify(bp_ctx* c, size_t count, bp_cs* const* vs, const uint
     VfyProvider<C> prov;
     prov.m_of = [&](size_t k) { return vs[k]->cs<C>()->V.size(); };
     prov.get = [&](size_t k, VfyInstance<C>& out) -> int { out.cs = vs[k]->cs<C>(); return BP_OK; };
+    // like-instances of one single-phase recording (bp_verifier_new_like): the device front end continues their transcripts from
+    // where Verifier::commit left them
+    prov.dev_batch = [&](VfyDevBatch<C>& db) -> bool {
+        const host::ConstraintSystem<C>* c0 = vs[0]->cs<C>();
+        if (!c0->base || !c0->tr) return false;
+        for (size_t k = 0; k < count; k++) {
+            const host::ConstraintSystem<C>* ck = vs[k]->cs<C>();
+            if (ck->base != c0->base || ck->cs_off.size() != 1 || !ck->deferred.empty() || ck->phase2 || ck->num_vars != c0->num_vars || ck->V.size() != c0->V.size() || !ck->tr) return false;
+        }
+        db.src = c0; db.m = c0->V.size(); db.absorb_commitments = false; db.shared_state = false;
+        db.state_of = [&](size_t k) { return (const host::Strobe*)&vs[k]->cs<C>()->tr->s; };
+        db.commit_xy = [&](size_t k) { return (const uint64_t*)vs[k]->cs<C>()->V.data(); };
+        return true;
+    };
     for (size_t k = 0; k < count; k++) { vs[k]->consumed = true; vs[k]->running = true; }
     const int rc = batch_verify_core<C>(c, count, prov, proofs, poff.data(), al.data(), timing, point_out);
     for (size_t k = 0; k < count; k++) vs[k]->running = false;
@@ -2068,6 +2103,13 @@ static int cs_batch_verify(bp_ctx* c, size_t count, bp_cs* const* vs, const uint
 // ---- debug hooks for the reference-held constants (src/util.rs:147-166, src/inner_product_proof.rs:556-562) ----
 // out[i] = x^i for i < n, through pow_table — the device function with which the prover / verifier kernels form y^i, y^-i and z^q
 // (the reference's exp_iter, util.rs:55-58).  xtab: x^(2^k), k < 32, resident words.
+template <class C> __global__ void k_dbg_scalars_to_ark(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    fe_store_ark<typename C::Fr>(w, load_fe_dev<typename C::Fr>(in + (size_t)i * 8));
+    store_words8(out + (size_t)i * 8, w);
+}
 template <class F> __global__ void k_dbg_exp_iter(const u32* __restrict__ xtab, u32 n, u32* __restrict__ out) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2314,7 +2356,11 @@ void bp_ctx_destroy(bp_ctx* c) {
                       &c->d_G, &c->d_H, &c->d_pc, &c->pc_table, &c->r_aL, &c->r_aR, &c->r_aO, &c->r_sL, &c->r_sR, &c->r_wL, &c->r_wR, &c->r_wO, &c->r_msmsc,
                       &c->r_ypow, &c->r_part, &c->r_small, &c->r_g, &c->r_h, &c->r_chal, &c->r_tail, &c->v_params, &c->v_gpart, &c->v_hpart, &c->v_alpha, &c->v_tables, &c->v_dec, &c->cyc_a, &c->cyc_b, &c->cyc_Gf, &c->cyc_Hf, &c->ftab_G, &c->ftab_H, &c->fb_G, &c->fb_H, &c->fb_pc, &c->p_moff, &c->p_ment, &c->p_mc, &c->p_coefs, &c->p_ztab, &c->fs_bcnt, &c->fs_loff, &c->fs_binch, &c->fs_sums};
     c->templates.clear();
+    c->vfe_classes.clear();
     for (auto b : bufs) b->release();
+    DevBuf* vbufs[] = {&c->vfe_in, &c->vfe_msg, &c->vfe_chal, &c->vfe_ws, &c->vfe_small};
+    for (auto b : vbufs) b->release();
+    if (c->h_vfe) (void)hipHostFree(c->h_vfe);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
     for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); if (c->vtail_ev[i]) (void)hipEventDestroy(c->vtail_ev[i]); if (c->dec_ev[i]) (void)hipEventDestroy(c->dec_ev[i]); }
@@ -2398,6 +2444,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
         case BP_TUNE_FOLD_QUAD_MAX: c->tune_fold_quad_max = (size_t)value; return BP_OK;
         case BP_TUNE_WAIT_SLEEP: if (value > 1000) return BP_E_ARG; c->tune_wait_sleep = value == 1 ? 30u : (unsigned)value; return BP_OK;
         case BP_TUNE_MSM_CHUNK_CAP: if (value && (value < 8 || value > 64)) return BP_E_ARG; c->tune_msm_chunk_cap = (size_t)value; return BP_OK;
+        case BP_TUNE_VFY_DEVICE: c->tune_vfy_device = value != 0; return BP_OK;
     }
     return BP_E_ARG;
 }
@@ -2969,6 +3016,72 @@ int bp_debug_decompress(bp_ctx* c, const uint8_t* compressed33, size_t n, uint64
         out_ok[i] = fl[i] == 0xFFu ? 0 : okv[i];
         if (out_ok[i]) { memcpy(out_xy + 8 * i, pts[i].x.v, 32); memcpy(out_xy + 8 * i + 4, pts[i].y.v, 32); } else memset(out_xy + 8 * i, 0, 64);
     }
+    return BP_OK;
+}
+
+// ---- verifier front end: test hooks (include/arkbp.h) ------------------------------------------------------------------------
+int bp_debug_vfe_schedule_replay(const uint8_t state203[203], int absorb_commitments, uint64_t m, uint32_t k, uint64_t n, const uint8_t* items, uint8_t* seeds_out,
+                                 uint32_t* nblocks_out) {
+    if (!state203 || !items || !seeds_out || k >= 32 || state203[200] >= host::Strobe::RATE || m > 65535) return BP_E_ARG;
+    vfe::Schedule sc;
+    if (!vfe::build_verifier_schedule(sc, state203[200], state203[201], absorb_commitments != 0, m, k, n)) { g_err = "vfe schedule: unsupported shape"; return BP_E_ARG; }
+    uint64_t st[25];
+    memcpy(st, state203, 200);
+    vfe::run_schedule_cpu(sc, st, items, seeds_out, [](uint64_t* s) { host::keccakf((host::u64*)s); });
+    if (nblocks_out) *nblocks_out = (uint32_t)sc.blocks.size();
+    return BP_OK;
+}
+int bp_debug_vfe_challenges(bp_ctx* c, size_t count, const uint8_t* proofs, size_t proof_len, const uint64_t* commit_xy, size_t m, const uint8_t* states203,
+                            int shared_state, int absorb_commitments, uint8_t* seeds_out, uint64_t* chal_out, uint32_t* status_out) {
+    if (!c || !count || !proofs || !states203 || !seeds_out || !chal_out || !status_out || (m && !commit_xy)) return BP_E_ARG;
+    if (proof_len < 539 || (proof_len - 539) % 66 || count > 65535 || m > 65535) return BP_E_ARG;
+    const size_t k = (proof_len - 539) / 66;
+    if (k >= 32) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t nst = shared_state ? 1 : count;
+    for (size_t i = 0; i < nst; i++) if (states203[203 * i + 200] != states203[200] || states203[203 * i + 201] != states203[201]) { g_err = "vfe: transcript positions differ"; return BP_E_ARG; }
+    vfe::Schedule sc;
+    if (!vfe::build_verifier_schedule(sc, states203[200], states203[201], absorb_commitments != 0, m, (uint32_t)k, (uint64_t)1 << k)) return BP_E_ARG;
+    const std::vector<uint32_t> enc = sc.encode();
+    vfe::Shape sh;
+    sh.P = (uint32_t)count; sh.m = (uint32_t)m; sh.nV = absorb_commitments ? (uint32_t)m : 0u; sh.k = (uint32_t)k; sh.plen = (uint32_t)proof_len;
+    sh.tail = (uint32_t)(6 + m + 5 + 2 * k); sh.nitems = sh.nV + 11 + 2 * (uint32_t)k + 3;
+    const size_t nch = 6 + k;
+    auto up256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_proofs = up256(count * proof_len), b_V = up256(count * m * 64), b_st = up256(nst * 200), b_sched = up256(enc.size() * 4);
+    BPCHK(c->vfe_in.ensure(b_proofs + b_V + b_st + b_sched));
+    BPCHK(c->vfe_msg.ensure((size_t)sh.nitems * vfe::ITEM_WORDS * count * 8));
+    BPCHK(c->vfe_chal.ensure(count * nch * 32));
+    BPCHK(c->vfe_ws.ensure(count * nch * 32 + count * nch * 32));
+    BPCHK(c->vfe_small.ensure(4096));
+    BPCHK(c->r_tail.ensure(count * sh.tail * 64));
+    uint8_t* d_in = (uint8_t*)c->vfe_in.p;
+    std::vector<uint8_t> states(nst * 200);
+    for (size_t i = 0; i < nst; i++) memcpy(&states[200 * i], states203 + 203 * i, 200);
+    HIPCHK(hipMemcpyAsync(d_in, proofs, count * proof_len, hipMemcpyHostToDevice, st));
+    if (m) HIPCHK(hipMemcpyAsync(d_in + b_proofs, commit_xy, count * m * 64, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_in + b_proofs + b_V, states.data(), nst * 200, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_in + b_proofs + b_V + b_st, enc.data(), enc.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c->vfe_small.p, 0, 256, st));
+    if (vfe::launch_points(c->curve, st, sh, d_in, (const u32*)(d_in + b_proofs), (uint64_t*)c->vfe_msg.p, c->r_tail.as<u32>(), c->vfe_small.as<u32>())) return BP_E_HIP;
+    uint8_t* d_seeds = (uint8_t*)c->vfe_ws.p;
+    u32* d_ark = c->vfe_ws.as<u32>() + count * nch * 8;
+    if (vfe::launch_sponge(c->curve, st, sh, (const u32*)(d_in + b_proofs + b_V + b_st), (const uint64_t*)(d_in + b_proofs + b_V), shared_state ? 0u : 25u, (const uint64_t*)c->vfe_msg.p,
+                           c->vfe_chal.as<u32>(), d_seeds)) return BP_E_HIP;
+    if (c->curve == 0) hipLaunchKernelGGL(k_dbg_scalars_to_ark<Secq>, dim3((u32)((count * nch + 255) / 256)), dim3(256), 0, st, c->vfe_chal.as<u32>(), d_ark, (u32)(count * nch));
+    else hipLaunchKernelGGL(k_dbg_scalars_to_ark<Zorro>, dim3((u32)((count * nch + 255) / 256)), dim3(256), 0, st, c->vfe_chal.as<u32>(), d_ark, (u32)(count * nch));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(seeds_out, d_seeds, count * nch * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(chal_out, d_ark, count * nch * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(status_out, c->vfe_small.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx_stream_wait(c));
+    return BP_OK;
+}
+int bp_ctx_vfe_stats(bp_ctx* c, uint64_t* device_batches, uint64_t* host_fallbacks) {
+    if (!c) return BP_E_ARG;
+    if (device_batches) *device_batches = c->vfe_batches;
+    if (host_fallbacks) *host_fallbacks = c->vfe_fallbacks;
     return BP_OK;
 }
 

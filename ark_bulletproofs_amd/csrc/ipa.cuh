@@ -21,44 +21,6 @@
 
 namespace arkbp {
 
-template <class F> __device__ __forceinline__ Fe load_fe_dev(const u32* p) {
-    u32 w[8];
-    load_words8(w, p);
-    return fe_unpack(w);
-}
-template <class F> __device__ __forceinline__ void store_fe_dev(u32* p, const Fe& a) {  // any L = 1, V < 32 value
-    u32 w[8];
-    fe_pack(w, fe_canon<F>(a));
-    store_words8(p, w);
-}
-template <class F> __device__ __forceinline__ void store_fe_canon(u32* p, const Fe& a) {
-    u32 w[8];
-    fe_store_canon<F>(w, a);
-    store_words8(p, w);
-}
-// lazy sum kept at L = 1, V <= 2
-template <class F> __device__ __forceinline__ Fe fe_addr(const Fe& a, const Fe& b) { return fe_wred<F>(fe_norm(fe_add(a, b))); }
-
-// workgroup tree-sum of one field element per lane (256 lanes); result valid in lane 0
-template <class F> __device__ __forceinline__ Fe block_sum_fe(Fe v, u32* sh /* 9*256 words */) {
-    const u32 tid = threadIdx.x;
-    for (u32 stride = 128; stride >= 1; stride >>= 1) {
-        if (tid >= stride && tid < 2 * stride) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) sh[i * 256 + tid] = v.l[i];
-        }
-        __syncthreads();
-        if (tid < stride) {
-            Fe o;
-#pragma unroll
-            for (int i = 0; i < 9; i++) o.l[i] = sh[i * 256 + tid + stride];
-            v = fe_addr<F>(v, o);
-        }
-        __syncthreads();
-    }
-    return v;
-}
-
 // ark-layout scalars (Montgomery R = 2^256) -> resident layout, and back
 template <class F> __global__ void k_scalars_import(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -78,18 +40,6 @@ template <class F> __global__ void k_scalars_export(const u32* __restrict__ in, 
 struct Words8 {
     u32 w[8];
 };
-// x^e from a table of x^(2^k) (resident words), e < 2^32
-template <class F> __device__ __forceinline__ Fe pow_table(const u32* __restrict__ tab, u32 e) {
-    if (!e) return fe_one<F>();
-    int k = __ffs((int)e) - 1;
-    Fe r = load_fe_dev<F>(tab + (size_t)k * 8);   // the lowest set bit costs a load, not a product
-    e >>= k + 1; k++;
-#pragma unroll 1
-    for (; e; k++, e >>= 1)
-        if (e & 1) r = fe_mul<F>(r, load_fe_dev<F>(tab + (size_t)k * 8));
-    return r;
-}
-
 // n = half length.  sL/sR: (2n+1) x 8 words each (canonical integers).  partials: gridDim.x x 2 x 8 words.
 template <class C> __global__ void __launch_bounds__(256)
 k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ Gf, const u32* __restrict__ Hf, int first, u32 n,

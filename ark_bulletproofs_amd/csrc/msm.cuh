@@ -20,6 +20,7 @@
 // Algorithmic bytes: 96 B per term (64 B affine base + 32 B scalar), SURVEY.md §8(d).
 #pragma once
 #include "ec.cuh"
+#include "fe_io.cuh"
 #include "ecq.cuh"
 #include "glv.cuh"
 
@@ -89,16 +90,6 @@ struct SlotPlan {
     u32 cap[MSM_MAXW];
 };
 
-__device__ __forceinline__ void load_words8(u32 w[8], const u32* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 a = q[0], b = q[1];
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-}
-__device__ __forceinline__ void store_words8(u32* p, const u32 w[8]) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
 __device__ __forceinline__ Aff load_aff_dev(const u32* p) {
     u32 w[16];
     load_words8(w, p);

@@ -901,3 +901,45 @@ Engine.rccl_init = _rccl_init
 Engine.rccl_shutdown = _rccl_shutdown
 Engine.collective_stats = _collective_stats
 Engine.debug_rccl_allgather = _debug_rccl_allgather
+
+
+# ---- verifier front end on the device (csrc/vfe.hip): test hooks ----------------------------------------------------------
+def vfe_schedule_replay(state203, absorb_commitments, m, k, n, items):
+    """CPU run of the data-independent sponge schedule of one verification (bp_debug_vfe_schedule_replay).  items: (count, 72)
+    uint8.  Returns ((6 + k, 32) uint8 challenge seeds, number of Keccak-f permutations)."""
+    items = np.ascontiguousarray(items, dtype=np.uint8)
+    seeds = np.zeros((6 + k, 32), dtype=np.uint8)
+    nb = C.c_uint32(0)
+    check(lib().bp_debug_vfe_schedule_replay(bytes(state203), int(bool(absorb_commitments)), C.c_uint64(m), C.c_uint32(k), C.c_uint64(n), ptr(items), ptr(seeds), C.byref(nb)),
+          "bp_debug_vfe_schedule_replay")
+    return seeds, nb.value
+
+
+def _debug_vfe_challenges(self, proofs, commitments, states203, absorb_commitments):
+    """k_vfe_points + k_vfe_sponge for same-shaped proofs.  proofs: list of equal-length bytes; commitments: (count, m, 8) uint64 ark
+    words; states203: one 203-byte state (shared) or one per proof.  Returns (seeds (count, 6 + k, 32) uint8,
+    challenges (count, 6 + k, 4) uint64 ark words, status)."""
+    count, plen = len(proofs), len(proofs[0])
+    assert all(len(p) == plen for p in proofs)
+    k = (plen - 539) // 66
+    V = np.ascontiguousarray(commitments, dtype=np.uint64).reshape(count, -1, 8)
+    m = V.shape[1]
+    shared = isinstance(states203, (bytes, bytearray))
+    st = bytes(states203) if shared else b"".join(bytes(s) for s in states203)
+    seeds = np.zeros((count, 6 + k, 32), dtype=np.uint8)
+    chal = np.zeros((count, 6 + k, 4), dtype=np.uint64)
+    status = C.c_uint32(0)
+    blob = b"".join(proofs)
+    check(lib().bp_debug_vfe_challenges(self.ctx, C.c_size_t(count), blob, C.c_size_t(plen), ptr(V) if m else None, C.c_size_t(m), st, int(shared), int(bool(absorb_commitments)),
+                                        ptr(seeds), ptr(chal), C.byref(status)), "bp_debug_vfe_challenges")
+    return seeds, chal, status.value
+
+
+def _vfe_stats(self):
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    check(lib().bp_ctx_vfe_stats(self.ctx, C.byref(a), C.byref(b)), "bp_ctx_vfe_stats")
+    return a.value, b.value
+
+
+Engine.debug_vfe_challenges = _debug_vfe_challenges
+Engine.vfe_stats = _vfe_stats

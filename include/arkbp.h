@@ -422,6 +422,8 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
                                      batch verification waits often and shortly: 10 us */
 #define BP_TUNE_MSM_CHUNK_CAP 9   /* entries per first-level chunk of the mid-size (fixed-shape) MSM pipeline: 8 .. 64; 0 = default (16 for callers that keep
                                      the GPU full; fitted per MSM to whole waves per SIMD for the bp_msm* entry points).  Results never depend on it */
+#define BP_TUNE_VFY_DEVICE 11    /* 1 (default): batch verification of like-instances of one single-phase statement runs its per-proof front end on the
+                                  * GPU (see "verifier front end on the device" below); 0: always the host replay (A/B, tests) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 
 /* The O(N) part of `Verifier::verification_scalars` (src/r1cs/verifier.rs:465-514, s from inner_product_proof.rs:279-311) for a
@@ -451,6 +453,30 @@ int bp_debug_decompress(bp_ctx* ctx, const uint8_t* compressed33, size_t n, uint
  * with t = t1 + lambda*t2 (mod r); lambda_out = canonical lambda.  The uniform IPA fold (src/inner_product_proof.rs:139-150)
  * runs its ladder over these 130-digit halves on secq256k1. */
 int bp_debug_glv_decompose(int curve, const uint64_t t[4], uint32_t masks[20], uint64_t lambda_out[4]);
+/* ---- verifier front end on the device (csrc/vfe.hip, csrc/vfe_sched.hpp) ------------------------------------------------------
+ * For a batch of like-instances of ONE single-phase statement bp_r1cs_batch_verify / bp_r1cs_batch_verify_scenarios run the
+ * per-proof front of `batch_verify` (src/r1cs/verifier.rs:604-691) on the GPU: R1CSProof::from_bytes' point decompression
+ * (src/r1cs/proof.rs:83-91), the merlin transcript replay of verification_scalars (verifier.rs:403-460, 516-519;
+ * src/inner_product_proof.rs:266-280; src/transcript.rs:45-102: Keccak-f[1600] / STROBE-128 / ChaCha20 -> Fr::rand) and the
+ * O(k + m) challenge arithmetic (:462-541).  Anything unusual (malformed bytes, an identity point that
+ * validate_and_append_point rejects, mixed shapes, randomized constraints) takes the host replay instead, which reports the
+ * reference's error.  ARKBP_VFY_HOST=1 in the environment forces the host replay (A/B).
+ *
+ * bp_debug_vfe_schedule_replay (host only, no GPU): builds the data-independent sponge schedule of one verification — transcript
+ * at state203 (bp_transcript_export_state), m commitments (absorbed as items 0..m-1 when absorb_commitments), k rounds, n = the
+ * padded multiplier count appended under "n" — and runs it on the CPU over `items` (72 bytes each: a 65-byte uncompressed point
+ * or a 32-byte scalar, zero padded; order: [commitments] A_I1 A_O1 S1 A_I2 A_O2 S2 T_1 T_3 T_4 T_5 T_6 L[k] R[k] t_x t_x_blinding
+ * e_blinding).  seeds_out: (6 + k) x 32 bytes, the challenge_bytes outputs y z u x w u_1..u_k r; *nblocks_out = permutations.
+ * bp_debug_vfe_challenges (GPU): the same through k_vfe_points + k_vfe_sponge for `count` proofs of one shape (proof_len bytes
+ * each; commit_xy count x m x 8 words, ark layout; states203: count x 203 bytes, or one when shared_state): seeds_out as above per
+ * proof, chal_out the derived challenge scalars (count x (6 + k) x 4 ark words), *status_out the OR of the kernels' reject bits
+ * (1 malformed, 2 identity under validation, 4 framing).
+ * bp_ctx_vfe_stats: batches the device front end completed / batches it handed to the host replay on this ctx. */
+int bp_debug_vfe_schedule_replay(const uint8_t state203[203], int absorb_commitments, uint64_t m, uint32_t k, uint64_t n, const uint8_t* items, uint8_t* seeds_out,
+                                 uint32_t* nblocks_out);
+int bp_debug_vfe_challenges(bp_ctx* ctx, size_t count, const uint8_t* proofs, size_t proof_len, const uint64_t* commit_xy, size_t m, const uint8_t* states203,
+                            int shared_state, int absorb_commitments, uint8_t* seeds_out, uint64_t* chal_out, uint32_t* status_out);
+int bp_ctx_vfe_stats(bp_ctx* ctx, uint64_t* device_batches, uint64_t* host_fallbacks);
 /* op: 0 P+Q (general add), 1 P+Q (mixed add), 2 2P, 3 k*P (k canonical, one per element) */
 int bp_debug_point_op(bp_ctx* ctx, int op, const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* k, uint64_t* out_xy, size_t n);
 

@@ -117,3 +117,27 @@ def test_rust_ffi_is_generated_from_the_header(lib):
     gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py")], capture_output=True, text=True, check=True).stdout
     assert gen == open(os.path.join(ROOT, "shim", "src", "ffi.rs")).read(), "run: python tools/gen_rust_ffi.py > shim/src/ffi.rs"
     assert sorted(re.findall(r"pub fn (bp_\w+)", gen)) == sorted(lib.EXPORTS)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(lib):
+    """with no librccl to bind, bp_rccl_unique_id / bp_ctx_rccl_init must return BP_E_HIP with a message (include/arkbp.h)
+    — the first version called dlerror() twice and dereferenced the NULL the second call returns.  Own process: the binding is
+    resolved once per process."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from ark_bulletproofs_amd import _lib\n"
+        "L = _lib.lib()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = L.bp_rccl_unique_id(buf)\n"
+        "msg = L.bp_last_error().decode()\n"
+        "print(rc, '|', msg)\n"
+        "assert rc == _lib.BP_E_HIP, rc\n"
+        "assert 'librccl not found' in msg and 'no-such-librccl' in msg, msg\n"
+    ) % ROOT
+    env = dict(os.environ, ARKBP_RCCL_LIB="/nonexistent/no-such-librccl.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
