@@ -2103,6 +2103,63 @@ static int cs_batch_verify(bp_ctx* c, size_t count, bp_cs* const* vs, const uint
 // ---- debug hooks for the reference-held constants (src/util.rs:147-166, src/inner_product_proof.rs:556-562) ----
 // out[i] = x^i for i < n, through pow_table — the device function with which the prover / verifier kernels form y^i, y^-i and z^q
 // (the reference's exp_iter, util.rs:55-58).  xtab: x^(2^k), k < 32, resident words.
+// host only: the challenge sequence of up to eight scenario verifications, from the per-proof live transcript (verify_prepare_t over
+// LiveTr) or from the lockstep replay (replay_challenges_x8) — both must follow ONE Fiat-Shamir schedule
+template <class C> struct LogLiveTr {
+    LiveTr<C> in;
+    std::vector<F4>* log;
+    void append_u64(const char* l, uint64_t x) { in.append_u64(l, x); }
+    bool vpoint(const char* l, const A4& p) { return in.vpoint(l, p); }
+    void point(const char* l, const A4& p) { in.point(l, p); }
+    void scalar(const char* l, const F4& x) { in.scalar(l, x); }
+    F4 chal(const char* l) { const F4 c = in.chal(l); log->push_back(c); return c; }
+    void ipp(uint64_t n) { in.ipp(n); }
+    F4 chal_r() { const F4 c = in.chal_r(); log->push_back(c); return c; }
+    bool inverse(F4&) { return false; }
+};
+template <class C>
+static int dbg_verify_challenges(size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs, const size_t* proof_lens, const uint64_t* commit_xy,
+                                 const size_t* ms, const uint64_t* publics, const size_t* npubs, int use_x8, uint64_t* out, size_t* nchal) {
+    std::vector<std::unique_ptr<host::Transcript>> trs(count);
+    std::vector<std::unique_ptr<host::ConstraintSystem<C>>> css(count);
+    std::vector<host::ProofData> pfs(count);
+    size_t po = 0, co = 0, uo = 0;
+    for (size_t k = 0; k < count; k++) {
+        host::StatementIO io;
+        io.commitments.resize(ms[k]); io.publics.resize(npubs[k]);
+        if (ms[k]) memcpy(io.commitments.data(), commit_xy + 8 * co, ms[k] * 64);
+        if (npubs[k]) memcpy(io.publics.data(), publics + 4 * uo, npubs[k] * 32);
+        trs[k].reset(new host::Transcript(host::scenario_label(scenarios[k])));
+        css[k].reset(new host::ConstraintSystem<C>());
+        BPCHK(build_verifier_cs<C>(*css[k], *trs[k], scenarios[k], params + 8 * k, io));
+        BPCHK(host::proof_from_bytes<C>(pfs[k], proofs + po, proof_lens[k]));
+        po += proof_lens[k]; co += ms[k]; uo += npubs[k];
+    }
+    if (use_x8) {
+#if defined(__x86_64__)
+        if (count != 8 || !host::cpu_has_avx512()) return 1;
+        host::ConstraintSystem<C>* csp[8]; const host::ProofData* pfp[8];
+        for (int j = 0; j < 8; j++) { csp[j] = css[j].get(); pfp[j] = &pfs[j]; }
+        std::vector<F4> ch[8];
+        if (!replay_challenges_x8<C>(csp, pfp, ch)) return 1;
+        for (int j = 0; j < 8; j++) { nchal[j] = ch[j].size(); if (ch[j].size() > 40) return BP_E_ARG; memcpy(out + (size_t)j * 40 * 4, ch[j].data(), ch[j].size() * 32); }
+        return BP_OK;
+#else
+        return 1;
+#endif
+    }
+    for (size_t k = 0; k < count; k++) {
+        std::vector<F4> log;
+        LogLiveTr<C> T{LiveTr<C>{*trs[k]}, &log};
+        VerifyPrep<C> vp;
+        const int rc = verify_prepare_t<C>(*css[k], pfs[k], (size_t)-1, vp, T);
+        if (rc) return rc;
+        if (log.size() > 40) return BP_E_ARG;
+        nchal[k] = log.size();
+        memcpy(out + k * 40 * 4, log.data(), log.size() * 32);
+    }
+    return BP_OK;
+}
 template <class C> __global__ void k_dbg_scalars_to_ark(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -3077,6 +3134,12 @@ int bp_debug_vfe_challenges(bp_ctx* c, size_t count, const uint8_t* proofs, size
     HIPCHK(hipMemcpyAsync(status_out, c->vfe_small.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx_stream_wait(c));
     return BP_OK;
+}
+int bp_debug_verify_challenges(int curve, size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs, const size_t* proof_lens,
+                               const uint64_t* commit_xy, const size_t* ms, const uint64_t* publics, const size_t* npubs, int use_x8, uint64_t* out, size_t* nchal) {
+    if (!count || count > 8 || !scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !publics || !npubs || !out || !nchal) return BP_E_ARG;
+    return curve == 0 ? dbg_verify_challenges<Secq>(count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, use_x8, out, nchal)
+                      : dbg_verify_challenges<Zorro>(count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, use_x8, out, nchal);
 }
 int bp_ctx_vfe_stats(bp_ctx* c, uint64_t* device_batches, uint64_t* host_fallbacks) {
     if (!c) return BP_E_ARG;

@@ -943,3 +943,17 @@ def _vfe_stats(self):
 
 Engine.debug_vfe_challenges = _debug_vfe_challenges
 Engine.vfe_stats = _vfe_stats
+
+
+def debug_verify_challenges(curve, instances, use_x8):
+    """host only: the challenge sequences of up to eight scenario verifications (bp_debug_verify_challenges).  Returns a list of
+    (nchal, 4) uint64 arrays, or None when the lockstep replay does not apply to the group."""
+    pk = instances if isinstance(instances, PackedInstances) else PackedInstances(instances)
+    out = np.zeros((pk.n, 40, 4), dtype=np.uint64)
+    nch = (C.c_size_t * pk.n)()
+    rc = lib().bp_debug_verify_challenges(curve, C.c_size_t(pk.n), pk.scen, ptr(pk.prm), pk.proofs, pk.plens, ptr(pk.cms), pk.ms, ptr(pk.pubs), pk.npubs, int(bool(use_x8)),
+                                          ptr(out), nch)
+    if rc == 1:
+        return None
+    check(rc, "bp_debug_verify_challenges")
+    return [out[j, : nch[j]].copy() for j in range(pk.n)]

@@ -1003,6 +1003,8 @@ def run_headline(args, rank, world, local):
     res["verify"] = ver
     if world > 1 and args.cfg5_logn > 0:
         res["cfg5"] = guarded_cfg5(args, rank, world, local, res)
+        if "error" in res["cfg5"]:
+            res.setdefault("errors", []).append("cfg5: " + res["cfg5"]["error"])
     return res
 
 
@@ -1016,13 +1018,13 @@ def guarded_cfg5(args, rank, world, local, res):
     limit = args.cfg5_timeout
     fallback_line = None
     if rank == 0:
-        fallback_line = json.dumps(dict(res, cfg5={"error": "the cfg5 leg did not finish within %d s (a rank failed or a collective did not complete); "
-                                                            "prove and verify above are complete" % limit}))
+        msg = "the cfg5 leg did not finish within %d s (a rank failed or a collective did not complete); prove and verify above are complete" % limit
+        fallback_line = json.dumps(dict(res, cfg5={"error": msg}, errors=["cfg5: " + msg]))
 
     def bail():
         if rank == 0:
             print(fallback_line, flush=True)
-        os._exit(0)
+        os._exit(3 if args.strict_exit else 0)
 
     timer = threading.Timer(limit, bail)
     timer.daemon = True
@@ -1070,6 +1072,7 @@ def main():
                     help="multi-GPU partition: msm workload: terms | Pippenger windows; prove workload: replicas (default) | windows = every rank proves the same statements with window-sharded MSMs")
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strict-exit", action="store_true", help="exit with status 3 (after printing the line) when a leg of the run failed, e.g. the multi-GPU cfg5 leg")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))        # this process has not touched the GPU
@@ -1090,7 +1093,10 @@ def main():
     if rank == 0:
         print(json.dumps(res), flush=True)
     if isinstance(res, dict) and isinstance(res.get("cfg5"), dict) and "error" in res["cfg5"]:
-        os._exit(0)        # (the other ranks may still sit in a collective of the failed leg: no orderly teardown is possible)
+        # (the other ranks may still sit in a collective of the failed leg: no orderly teardown is possible.)  The failure is in the
+        # line ("cfg5.error" and the top-level "errors"); --strict-exit also turns it into exit status 3 for launchers that only look
+        # at the status — the default stays 0 so that a scaling run keeps its complete prove / verify halves.
+        os._exit(3 if args.strict_exit else 0)
     if world > 1:
         import torch.distributed as dist
 

@@ -477,6 +477,14 @@ int bp_debug_vfe_schedule_replay(const uint8_t state203[203], int absorb_commitm
 int bp_debug_vfe_challenges(bp_ctx* ctx, size_t count, const uint8_t* proofs, size_t proof_len, const uint64_t* commit_xy, size_t m, const uint8_t* states203,
                             int shared_state, int absorb_commitments, uint8_t* seeds_out, uint64_t* chal_out, uint32_t* status_out);
 int bp_ctx_vfe_stats(bp_ctx* ctx, uint64_t* device_batches, uint64_t* host_fallbacks);
+/* host only (no GPU): the Fiat-Shamir challenges y z u x w u_1..u_k r of up to eight scenario verifications (flat arrays as in
+ * bp_r1cs_batch_verify_scenarios), derived by the per-proof live transcript replay (use_x8 = 0: verify_prepare over the instance's own
+ * merlin transcript, src/r1cs/verifier.rs:403-460 + :516-519) or by the lockstep replay of eight same-shaped single-phase instances
+ * (use_x8 = 1; AVX-512 Keccak-f x8).  out: count x 40 x 4 ark words, nchal[j] = challenges of instance j.  Returns 1 (not an error
+ * code) when the lockstep replay does not apply: fewer than eight instances, differing shapes, a randomized phase, no AVX-512. */
+int bp_debug_verify_challenges(int curve, size_t count, const int* scenarios, const uint64_t* params, const uint8_t* proofs, const size_t* proof_lens,
+                               const uint64_t* commit_xy, const size_t* ms, const uint64_t* publics, const size_t* npubs, int use_x8, uint64_t* out,
+                               size_t* nchal);
 /* op: 0 P+Q (general add), 1 P+Q (mixed add), 2 2P, 3 k*P (k canonical, one per element) */
 int bp_debug_point_op(bp_ctx* ctx, int op, const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* k, uint64_t* out_xy, size_t n);
 

@@ -433,6 +433,15 @@ where FF: 'static + Fn(&mut RandomizingCs<G>) -> Result<(), R1CSError> {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+/// The engine works with `PedersenGens::default()` (it derives B and B_blinding itself, `bp_pedersen_gens`): a caller with custom
+/// Pedersen generators must not be checked against the default ones silently.  Prover::new, Verifier::verify and batch_verify all
+/// assert it (the reference would use `pc_gens.B` / `pc_gens.B_blinding`, verifier.rs:574-576).
+fn assert_default_pc_gens<G: GpuCurve>(pc_gens: &PedersenGens<G>) {
+    let (mut b, mut bb) = ([0u64; 8], [0u64; 8]);
+    unsafe { ffi::bp_pedersen_gens(G::CURVE_ID, b.as_mut_ptr(), bb.as_mut_ptr()) };
+    assert!(G::point_words(&pc_gens.B) == b && G::point_words(&pc_gens.B_blinding) == bb, "the engine works with PedersenGens::default()");
+}
+
 // r1cs::Prover (src/r1cs/prover.rs)
 // ------------------------------------------------------------------------------------------------------------------------------
 pub struct Prover<'g, G: GpuCurve, T: BorrowMut<Transcript>> {
@@ -442,9 +451,7 @@ pub struct Prover<'g, G: GpuCurve, T: BorrowMut<Transcript>> {
 impl<'g, G: GpuCurve, T: BorrowMut<Transcript>> Prover<'g, G, T> {
     /// `Prover::new(pc_gens, transcript)` (prover.rs:291-308)
     pub fn new(pc_gens: &'g PedersenGens<G>, transcript: T) -> Self {
-        let (mut b, mut bb) = ([0u64; 8], [0u64; 8]);
-        unsafe { ffi::bp_pedersen_gens(G::CURVE_ID, b.as_mut_ptr(), bb.as_mut_ptr()) };
-        assert!(G::point_words(&pc_gens.B) == b && G::point_words(&pc_gens.B_blinding) == bb, "the engine works with PedersenGens::default()");
+        assert_default_pc_gens::<G>(pc_gens);
         Prover { rec: Recorder::new(true, transcript), _pc_gens: pc_gens }
     }
     /// `commit(v, v_blinding) -> (V, Variable)` (prover.rs:327-341)
@@ -510,7 +517,8 @@ impl<G: GpuCurve, T: BorrowMut<Transcript>> Verifier<G, T> {
         var_in(var)
     }
     /// `verify(self, proof, pc_gens, bp_gens)` (verifier.rs:549-557)
-    pub fn verify(mut self, proof: &R1CSProof<G>, _pc_gens: &PedersenGens<G>, bp_gens: &BulletproofGens<G>) -> Result<(), R1CSError> {
+    pub fn verify(mut self, proof: &R1CSProof<G>, pc_gens: &PedersenGens<G>, bp_gens: &BulletproofGens<G>) -> Result<(), R1CSError> {
+        assert_default_pc_gens::<G>(pc_gens);
         self.rec.sync_to_engine();
         let bytes = proof.to_bytes().map_err(|_| R1CSError::FormatError)?;
         let rc = with_ctx::<G, _>(|ctx| {
@@ -541,13 +549,17 @@ impl<G: GpuCurve, T: BorrowMut<Transcript>> RandomizableConstraintSystem<G::Scal
 
 /// `batch_verify(prng, instances, pc_gens, bp_gens)` (verifier.rs:604-691): one weight per instance drawn from `prng` in instance
 /// order (:649), all instances in ONE library call (block pipeline + one mega-check MSM).
-pub fn batch_verify<'a, G, I, R, T>(prng: &mut R, instances: I, _pc_gens: &PedersenGens<G>, bp_gens: &BulletproofGens<G>) -> Result<(), R1CSError>
+/// Difference from the reference in what `prng` has consumed AFTER AN ERROR: the reference draws an instance's weight only after
+/// that instance's verification_scalars succeeded (:617-649) and returns on the first failure, so after an error fewer draws were
+/// made; here every weight is drawn before the one library call.  On success the draws are identical.
+pub fn batch_verify<'a, G, I, R, T>(prng: &mut R, instances: I, pc_gens: &PedersenGens<G>, bp_gens: &BulletproofGens<G>) -> Result<(), R1CSError>
 where
     G: GpuCurve,
     R: CryptoRng + RngCore,
     T: BorrowMut<Transcript>,
     I: IntoIterator<Item = (Verifier<G, T>, &'a R1CSProof<G>)>,
 {
+    assert_default_pc_gens::<G>(pc_gens);
     let mut verifiers: Vec<Verifier<G, T>> = Vec::new();
     let mut bytes: Vec<u8> = Vec::new();
     let mut lens: Vec<usize> = Vec::new();

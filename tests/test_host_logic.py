@@ -252,3 +252,35 @@ def test_product_lockstep_challenges_equal_scalar_challenges(E, prefix, msg_len,
         b[l].append_message(b"after", b"z" * 170)
         assert a[l].challenge_bytes(b"c", 40) == b[l].challenge_bytes(b"c", 40), l
     assert len({bytes(got[l]) for l in range(8)}) == 8
+
+
+def test_lockstep_replay_schedule_equals_live_transcript(oracle):
+    """replay_challenges_x8 re-states verify_prepare_t's Fiat-Shamir schedule (labels, the "m" / "n" encodings, the
+    1-phase separator, message order) for eight transcripts in lockstep; any edit to one copy would silently desynchronise the
+    challenges.  CPU-only comparison of both on proofs from the oracle's prover, both curves; a group with a differing round count
+    and a group with a randomized (two-phase) statement must be declined, not mis-replayed."""
+    from ark_bulletproofs_amd import engine as E
+
+    O = oracle
+    for cv in (0, 1):
+        inst = []
+        for j in range(8):
+            pr = O.r1cs_prove(cv, O.SC_MULTI_RANGE, [3, 8, 0], bytes([30 + j]) * 32, 64, m_cap=8)
+            assert pr.rc == 0
+            inst.append((O.SC_MULTI_RANGE, [3, 8, 0], pr.proof, pr.commitments, pr.publics))
+        live = E.debug_verify_challenges(cv, inst, False)
+        x8 = E.debug_verify_challenges(cv, inst, True)
+        assert all(len(c) == 6 + 5 for c in live)          # y z u x w, u_1..u_5 (n = 24 -> 32), r
+        if x8 is None:
+            pytest.skip("no AVX-512 on this host: the lockstep replay is not used")
+        for a, b in zip(live, x8):
+            assert (a == b).all(), "lockstep replay and live transcript disagree"
+        # a lane with another round count: declined
+        pr = O.r1cs_prove(cv, O.SC_MULTI_RANGE, [3, 4, 0], bytes([77]) * 32, 64, m_cap=8)
+        odd = list(inst); odd[5] = (O.SC_MULTI_RANGE, [3, 4, 0], pr.proof, pr.commitments, pr.publics)
+        assert E.debug_verify_challenges(cv, odd, True) is None
+        assert len(E.debug_verify_challenges(cv, odd, False)[5]) == 6 + 4
+        # a two-phase lane (the shuffle gadget's randomized constraints): declined
+        pr = O.r1cs_prove(cv, O.SC_SHUFFLE, [4], bytes([78]) * 32, 64, m_cap=16)
+        odd = list(inst); odd[2] = (O.SC_SHUFFLE, [4], pr.proof, pr.commitments, pr.publics)
+        assert E.debug_verify_challenges(cv, odd, True) is None
