@@ -214,14 +214,15 @@ def fake(args, rank, world, local):
         time.sleep(60)
     raise RuntimeError("rank failed in the cfg5 leg")
 bench.run_cfg5 = fake
-args = argparse.Namespace(cfg5_timeout=1)
+args = argparse.Namespace(cfg5_timeout=1, strict_exit=(sys.argv[2] == "strict"))
 res = {"metric": "m", "value": 1.0, "verify": {"value": 2.0}}
 res["cfg5"] = bench.guarded_cfg5(args, 0, 2, 0, res)
 print(json.dumps(res), flush=True)
 """ % root
-    for mode in ("hang", "raise"):
-        out = subprocess.run([sys.executable, "-c", prog, mode], capture_output=True, text=True, timeout=50)
-        assert out.returncode == 0, out.stderr[-500:]
+    for mode, strict in (("hang", "lenient"), ("raise", "lenient"), ("hang", "strict")):
+        out = subprocess.run([sys.executable, "-c", prog, mode, strict], capture_output=True, text=True, timeout=50)
+        # the line always comes; --strict-exit also reports the failed leg through the exit status (ADVICE r03)
+        assert out.returncode == (3 if strict == "strict" else 0), out.stderr[-500:]
         lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, out.stdout
         d = json.loads(lines[0])
