@@ -36,6 +36,55 @@ using arkbp::host::J4;
 static thread_local std::string g_err;
 const char* bp_last_error(void) { return g_err.c_str(); }
 
+// ---- host-only dry run (sanitizer builds on machines without a GPU; include/arkbp.h bp_debug_ctx_create_hostonly) ------------------
+// A ctx created without a device runs the HOST side of batch verification — framing, thread pools, shared recordings, transcript
+// replay, template cache and eviction, staging — with every HIP call replaced: "device" buffers are zeroed host memory, copies are
+// memcpy, kernels / streams / events are skipped.  Nothing is verified in that mode (the entry points return a checksum of what the
+// host staged instead of the mega-check); it exists so that ASan / UBSan / TSan see the multi-threaded host layer (tools/sanitize/).
+// g_dry is set, per calling thread, by the entry points that accept such a ctx; the library's own pool threads make no HIP calls.
+static thread_local bool g_dry = false;
+namespace dry {
+static char g_token;   // stands for streams and events
+template <class T> static inline hipError_t Malloc(T** p, size_t n) { if (g_dry) { *p = (T*)calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; } return ::hipMalloc(p, n); }
+static inline hipError_t Free(void* p) { if (g_dry) { free(p); return hipSuccess; } return ::hipFree(p); }
+template <class T> static inline hipError_t HostMalloc(T** p, size_t n, unsigned flags = hipHostMallocDefault) { if (g_dry) { *p = (T*)calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; } return ::hipHostMalloc(p, n, flags); }
+static inline hipError_t HostFree(void* p) { if (g_dry) { free(p); return hipSuccess; } return ::hipHostFree(p); }
+static inline hipError_t MemcpyAsync(void* d, const void* s_, size_t n, hipMemcpyKind k, hipStream_t st) { if (g_dry) { if (n) memmove(d, s_, n); return hipSuccess; } return ::hipMemcpyAsync(d, s_, n, k, st); }
+static inline hipError_t MemsetAsync(void* d, int v, size_t n, hipStream_t st) { if (g_dry) { if (n) memset(d, v, n); return hipSuccess; } return ::hipMemsetAsync(d, v, n, st); }
+static inline hipError_t GetLastError() { return g_dry ? hipSuccess : ::hipGetLastError(); }
+static inline hipError_t SetDevice(int d) { return g_dry ? hipSuccess : ::hipSetDevice(d); }
+static inline hipError_t StreamSynchronize(hipStream_t st) { return g_dry ? hipSuccess : ::hipStreamSynchronize(st); }
+static inline hipError_t StreamCreateWithFlags(hipStream_t* st, unsigned f) { if (g_dry) { *st = (hipStream_t)&g_token; return hipSuccess; } return ::hipStreamCreateWithFlags(st, f); }
+static inline hipError_t StreamDestroy(hipStream_t st) { return g_dry ? hipSuccess : ::hipStreamDestroy(st); }
+static inline hipError_t EventCreate(hipEvent_t* e) { if (g_dry) { *e = (hipEvent_t)&g_token; return hipSuccess; } return ::hipEventCreate(e); }
+static inline hipError_t EventCreateWithFlags(hipEvent_t* e, unsigned f) { if (g_dry) { *e = (hipEvent_t)&g_token; return hipSuccess; } return ::hipEventCreateWithFlags(e, f); }
+static inline hipError_t EventDestroy(hipEvent_t e) { return g_dry ? hipSuccess : ::hipEventDestroy(e); }
+static inline hipError_t EventRecord(hipEvent_t e, hipStream_t st) { return g_dry ? hipSuccess : ::hipEventRecord(e, st); }
+static inline hipError_t EventSynchronize(hipEvent_t e) { return g_dry ? hipSuccess : ::hipEventSynchronize(e); }
+static inline hipError_t EventQuery(hipEvent_t e) { return g_dry ? hipSuccess : ::hipEventQuery(e); }
+static inline hipError_t EventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { if (g_dry) { *ms = 0; return hipSuccess; } return ::hipEventElapsedTime(ms, a, b); }
+}  // namespace dry
+#define hipMalloc(...) dry::Malloc(__VA_ARGS__)
+#define hipFree(...) dry::Free(__VA_ARGS__)
+#define hipHostMalloc(...) dry::HostMalloc(__VA_ARGS__)
+#define hipHostFree(...) dry::HostFree(__VA_ARGS__)
+#define hipMemcpyAsync(...) dry::MemcpyAsync(__VA_ARGS__)
+#define hipMemsetAsync(...) dry::MemsetAsync(__VA_ARGS__)
+#define hipGetLastError(...) dry::GetLastError(__VA_ARGS__)
+#define hipSetDevice(...) dry::SetDevice(__VA_ARGS__)
+#define hipStreamSynchronize(...) dry::StreamSynchronize(__VA_ARGS__)
+#define hipStreamCreateWithFlags(...) dry::StreamCreateWithFlags(__VA_ARGS__)
+#define hipStreamDestroy(...) dry::StreamDestroy(__VA_ARGS__)
+#define hipEventCreate(...) dry::EventCreate(__VA_ARGS__)
+#define hipEventCreateWithFlags(...) dry::EventCreateWithFlags(__VA_ARGS__)
+#define hipEventDestroy(...) dry::EventDestroy(__VA_ARGS__)
+#define hipEventRecord(...) dry::EventRecord(__VA_ARGS__)
+#define hipEventSynchronize(...) dry::EventSynchronize(__VA_ARGS__)
+#define hipEventQuery(...) dry::EventQuery(__VA_ARGS__)
+#define hipEventElapsedTime(...) dry::EventElapsedTime(__VA_ARGS__)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(...) do { if (!g_dry) { hipLaunchKernelGGLInternal(__VA_ARGS__); } } while (0)
+
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
         hipError_t e_ = (x);                                                                        \
@@ -170,6 +219,7 @@ struct IpaState {
 
 struct bp_ctx {
     int curve = 0, device = 0;
+    bool host_only = false;      // no device behind this ctx: the host-side dry run of batch verification (see g_dry)
     hipStream_t stream = nullptr;
     bool profiling = false;
     size_t tune_fold_batch_min = 65536;   // BP_TUNE_FOLD_BATCH_MIN
@@ -2402,6 +2452,8 @@ int bp_ctx_create(int curve, int device, bp_ctx** out) {
 }
 void bp_ctx_destroy(bp_ctx* c) {
     if (!c) return;
+    g_dry = c->host_only;
+    c->pool.reset();             // (the pool's threads end before the buffers they may have touched go away)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     collect_timers(c);
@@ -2431,6 +2483,15 @@ void bp_ctx_destroy(bp_ctx* c) {
     if (c->h_coll) (void)hipHostFree(c->h_coll);
     (void)hipStreamDestroy(c->stream);
     delete c;
+    g_dry = false;
+}
+int bp_debug_ctx_create_hostonly(int curve, size_t gens_capacity, bp_ctx** out) {
+    if (!out || (curve != BP_CURVE_SECQ256K1 && curve != BP_CURVE_ZORRO)) return BP_E_ARG;
+    bp_ctx* c = new bp_ctx();
+    c->curve = curve; c->device = -1; c->host_only = true; c->gens_cap = gens_capacity;
+    c->stream = (hipStream_t)&dry::g_token;
+    *out = c;
+    return BP_OK;
 }
 int bp_ctx_set_window_shard(bp_ctx* c, int rank, int world, bp_point_reduce_cb cb, void* user) {
     if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !cb)) return BP_E_ARG;
@@ -2808,10 +2869,13 @@ int bp_r1cs_batch_verify_scenarios(bp_ctx* c, size_t count, const int* scenarios
     if (!c) return BP_E_ARG;
     if (count == 0) { if (check_point_xy) memset(check_point_xy, 0, 64); return BP_OK; }   // the reference's mega-check of nothing is the identity (verifier.rs:685-690)
     if (!scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !npubs || !alpha_seed) return BP_E_ARG;
+    g_dry = c->host_only;
     HIPCHK(hipSetDevice(c->device));
-    if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; return BP_E_GENS_LENGTH; }
-    return c->curve == 0 ? batch_verify_scenarios<Secq>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy)
-                         : batch_verify_scenarios<Zorro>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy);
+    if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; g_dry = false; return BP_E_GENS_LENGTH; }
+    const int rc = c->curve == 0 ? batch_verify_scenarios<Secq>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy)
+                                 : batch_verify_scenarios<Zorro>(c, count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, alpha_seed, timing, alpha_skip, check_point_xy);
+    g_dry = false;
+    return rc;
 }
 
 // ---- statements: Prover::new + commits + gadget, separated from prove() ----------------------------------
@@ -2986,10 +3050,13 @@ int bp_r1cs_batch_verify(bp_ctx* c, size_t count, bp_cs* const* verifiers, const
         std::sort(sorted.begin(), sorted.end(), std::less<const bp_cs*>());
         if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) { g_err = "batch_verify: a verifier is consumed by ONE instance"; return BP_E_ARG; }
     }
+    g_dry = c->host_only;
     HIPCHK(hipSetDevice(c->device));
-    if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; return BP_E_GENS_LENGTH; }
-    return c->curve == 0 ? cs_batch_verify<Secq>(c, count, verifiers, proofs, proof_lens, alphas, timing, check_point_xy)
-                         : cs_batch_verify<Zorro>(c, count, verifiers, proofs, proof_lens, alphas, timing, check_point_xy);
+    if (!c->gens_cap) { g_err = "batch_verify: generators not installed"; g_dry = false; return BP_E_GENS_LENGTH; }
+    const int rc = c->curve == 0 ? cs_batch_verify<Secq>(c, count, verifiers, proofs, proof_lens, alphas, timing, check_point_xy)
+                                 : cs_batch_verify<Zorro>(c, count, verifiers, proofs, proof_lens, alphas, timing, check_point_xy);
+    g_dry = false;
+    return rc;
 }
 int bp_verifier_verify(bp_ctx* c, bp_cs* v, const uint8_t* proof, size_t proof_len) {
     return bp_r1cs_batch_verify(c, 1, &v, proof, &proof_len, nullptr, nullptr, nullptr);

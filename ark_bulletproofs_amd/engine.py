@@ -42,6 +42,16 @@ class Engine:
         self.ctx = C.c_void_p()
         check(lib().bp_ctx_create(curve, device, C.byref(self.ctx)), "bp_ctx_create")
 
+    @classmethod
+    def host_only(cls, curve=SECQ256K1, gens_capacity=256):
+        """a ctx WITHOUT a device (bp_debug_ctx_create_hostonly): the host side of batch verification as a dry run, for sanitizer
+        builds on machines with no GPU.  Nothing is verified in that mode."""
+        self = cls.__new__(cls)
+        self.curve = curve
+        self.ctx = C.c_void_p()
+        check(lib().bp_debug_ctx_create_hostonly(curve, C.c_size_t(gens_capacity), C.byref(self.ctx)), "bp_debug_ctx_create_hostonly")
+        return self
+
     def close(self):
         if self.ctx:
             lib().bp_ctx_destroy(self.ctx)

@@ -56,7 +56,9 @@ def valu_entry(products, seconds, note):
     return {"unit": "G modmul/s", "achieved": rate, "peak": VALU_PEAK_GMODMUL, "frac": rate / VALU_PEAK_GMODMUL,
             "measured_rate": VALU_MEASURED_GMODMUL, "frac_of_measured_rate": rate / VALU_MEASURED_GMODMUL,
             "products": products, "valu_instructions": products * VALU_INSTR_PER_PRODUCT,
-            "peak_derivation": "256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / (162 v_mad_u64_u32 x 4 cyc + 100 full-rate x 2 cyc)", "note": note}
+            "peak_derivation": "256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / (162 v_mad_u64_u32 x 4 cyc + 100 full-rate x 2 cyc); the 4 cycles per "
+                               "v_mad_u64_u32 are MEASURED here (tools/ubench.hip, profiles/r01_ubench_radix29.txt: 0.95 wave-instructions per clock and CU) — the "
+                               "guide has no row for that instruction; clocks, SIMD count and the 2-cycle full-rate issue are the guide's", "note": note}
 
 
 def kernel_entry(name, ms, launches, alg_bytes, traffic, products, note=""):
@@ -259,7 +261,7 @@ def mem_limit_bytes():
     return 64 << 30
 
 
-def pmc_traffic(keys, applicable, fname, field="largest"):
+def pmc_traffic(keys, applicable, fname, field="largest", raw_fetch=False):
     """HBM bytes from the committed rocprofv3 PMC passes (profiles/<fname>, made by tools/pmc_summary.py from FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same workload).  FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950
     tallies 128-B requests at 64 B for 16-B-per-lane loads); WRITE_SIZE is taken as is.  field = "largest": the dispatch with the
@@ -275,7 +277,10 @@ def pmc_traffic(keys, applicable, fname, field="largest"):
             # instantiations with further template arguments, "name<Curve, false>")
             for kk in d:
                 if kk == k or kk.startswith(k[:-1] + ","):
-                    tot += (2.0 * d[kk]["fetch_KiB_" + field] + d[kk]["write_KiB_" + field]) * 1024.0
+                    # raw_fetch: kernels whose reads are 64-byte random gathers (one affine point per lane): the guide's doubling is for
+                    # wide coalesced 16-B-per-lane loads; tools/ubench.hip `gather64` calibrates FETCH_SIZE at 1.0x for this shape
+                    # (profiles/r04_fetch_calibration.txt)
+                    tot += ((1.0 if raw_fetch else 2.0) * d[kk]["fetch_KiB_" + field] + d[kk]["write_KiB_" + field]) * 1024.0
                     found += 1
         return tot if found else None
     except Exception:
@@ -517,6 +522,11 @@ def run_prove(args, rank, world, local):
 
         free_b, _ = torch.cuda.mem_get_info(local)
         budget = int(free_b) - P * 3000 * N - (12 << 30)        # (the fixed-base MSM rows are installed already)
+        # ... and a cap on what the tables may take: the width sweep of round 4 (profiles/r04_fold_table_width_sweep.txt: w = 8 / 219 GB
+        # 23.9 M constraints/s, w = 7 / 122 GB 23.6, w = 6 / 71 GB 23.0, w = 5 / 44 GB 22.8, w = 4 / 27 GB 21.9) puts the smallest width
+        # within 2 % of the best at w = 7: 125 GB leaves more than half of the HBM to whatever shares the GPU (the batch verifier does)
+        if args.fold_table_budget_gb > 0:
+            budget = min(budget, int(args.fold_table_budget_gb * 1e9))
         # bases [0, 3N/4): the first TWO fold rounds come straight from the tables (bases [0, N/2) would serve the first round only)
         tab_count = N * 3 // 4 if (args.fold_tables >= 2 and not window_sharded) else N // 2
         wbits, nbytes = engs[0].gens_fold_tables(tab_count, window_bits=args.fold_table_bits, budget_bytes=max(budget, 1 << 30))
@@ -603,8 +613,12 @@ def run_prove(args, rank, world, local):
     engs[0].set_profiling(True)     # (HIP events only here: the timed pipeline above runs without them)
     engs[0].reset_profiling()
     iso = E.Statement(args.curve, E.SC_SQUARE_CHAIN, [N, 0], statement_seed(120, 0))
-    iso.precompute()
+    t_iso = time.perf_counter()
+    iso.precompute()                                 # the TranscriptRng head of prove(): sequential by the reference's construction, one core
+    rng_head_ms = (time.perf_counter() - t_iso) * 1e3
+    t_iso = time.perf_counter()
     iso.prove(engs[0])
+    alone_ms = (time.perf_counter() - t_iso) * 1e3   # everything after the head, this proof alone on the GPU (with HIP-event profiling on)
     iso.free()
     fold_ms, fold_n = engs[0].kernel_time(3)
     acc_ms = engs[0].kernel_time(0)[0]
@@ -621,7 +635,11 @@ def run_prove(args, rank, world, local):
                    "curve": CURVES[args.curve], "parallelism": ("window-sharded x%d" if window_sharded else "replicas x%d") % world,
                    "verified": verified, "verified_note": "timed proofs 0 and %d verified on the GPU after the timed region, a tampered copy of each rejected" % (nproofs - 1),
                    "table_entries_failing_check": tables_bad, "tables_check_s": t_chk if tables_bad is not None else None, "collectives": coll_info,
-                   "pipeline_thread_seconds_per_wall_second": pipe_util, "host_cpu_in_timed_region": host_cpu, "host_cpu": host_cpu_info(), "single_proof_latency_ms": float(stages[0]) / nproofs * 1e3, "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
+                   "pipeline_thread_seconds_per_wall_second": pipe_util, "host_cpu_in_timed_region": host_cpu, "host_cpu": host_cpu_info(),
+                   "in_pipeline_latency_ms": float(stages[0]) / nproofs * 1e3, "alone_ms_after_rng_head": alone_ms, "rng_head_ms": rng_head_ms,
+                   "latency_note": "in_pipeline: mean prove() wall of a proof with %d proofs in flight; alone: one proof on an otherwise idle GPU after its "
+                                   "TranscriptRng head; rng_head: that head (merlin's sequential sponge, prover.rs:483-513) on one host core" % P,
+                   "gens_derive_s": t_gens, "first_round_fold_tables": tab_info, "fixed_base_msm_tables": msm_tab_info,
                    "per_proof_stage_ms": {k: float(v) / nproofs * 1e3 for k, v in zip(names, stages) if k != "-"}},
     }
     if fold_n:
@@ -659,13 +677,23 @@ def run_prove(args, rank, world, local):
         secq20 = args.logn == 20 and args.curve == 0 and bool(args.fold_tables)
         pf = "r02_pmc_prove2p20_summary.json"
 
-        def tr(keys, field="all_launches"):
-            return pmc_traffic(keys, secq20, pf, field)
+        def tr(keys, field="all_launches", raw_fetch=False):
+            return pmc_traffic(keys, secq20, pf, field, raw_fetch=raw_fetch)
 
         # MSM terms of one proof: commitments (2n+1) + (n+1) + (2n+1), then L and R of every round: 2 * (2 n_j + 1)
         msm_terms = (5 * N + 3) + sum(2 * (2 * (N >> (j + 1)) + 1) for j in range(args.logn))
         cW = E.msm_window_count(args.curve, max(N, 64))
         madds_per_term = (255 if args.curve else 256) // cW[1]       # ordinary schedule; the fixed-base schedule needs fewer (c = 20)
+        # the accumulate launches split the proof's MSM terms: the fixed-base / large-bucket kernel takes the commitments and the L / R of
+        # the rounds whose MSMs have >= 2^18 buckets or run over the generator tables; the fixed-shape pipeline the mid-size rest
+        two_rounds = bool(tab_info and tab_info.get("rounds_from_tables") == 2)
+        lr_terms = [2 * (2 * (N >> (j + 1)) + 1) for j in range(args.logn)]
+        big_rounds = 2 if two_rounds else 1
+        terms_big = (5 * N + 3) + (lr_terms[0] + (2 * (5 * N // 4 + 1) if two_rounds else 0)) + sum(t for t in lr_terms[big_rounds:] if t // 2 >= (1 << 18))
+        freeze_len = 8192
+        terms_fs = sum((t if (N >> (j + 1)) >= freeze_len else 2 * (2 * freeze_len + 1)) for j, t in enumerate(lr_terms) if j >= big_rounds and t // 2 < (1 << 18))
+        madds_big = terms_big * (13 if msm_tab_info else madds_per_term)
+        madds_fs = (255 if args.curve else 256) // E.msm_window_count(args.curve, 1 << 16)[1]
         kernels = [
             kernel_entry("k_ipa_fold_tab | k_ipa_fold_tab2 (rounds 1-2: fixed-base table look-ups)", tab_ms, tab_n, 576.0 * (N // 2) * (1.5 if (tab_info and tab_info.get("rounds_from_tables") == 2) else 1.0),
                          tr(["prove2p20/k_ipa_fold_tab<Secq>", "prove2p20/k_ipa_fold_tab2<Secq>"]), prod_tab,
@@ -675,16 +703,28 @@ def run_prove(args, rank, world, local):
                          tr("prove2p20/k_ipa_fold_glv<Secq>"), prod_lad, "a round below 2^16 lanes takes ~1.15 ms whatever its size: one lane's serial ladder"),
             kernel_entry("k_ipa_fold_finish (Jacobian -> affine, one inversion per 8 points)", fin_ms, fin_n, 2.0 * (N - 1) * (96 + 64), tr("prove2p20/k_ipa_fold_finish<Secq>"), prod_fin,
                          "re-reads the Jacobian results the ladders wrote (unfused: 0.58 GB per proof, 0.07 ms at HBM speed)"),
-            kernel_entry("k_msm_accum (MSMs above 2^18 buckets and the fixed-base MSMs)", acc_ms, acc_n, None, tr("prove2p20/k_msm_accum<Secq>"), None),
-            kernel_entry("k_msm_accum_fs (fixed-shape pipeline: the mid-size L / R MSMs)", accfs_ms, accfs_n, None, tr("prove2p20/k_msm_accum_fs<Secq>"), None),
+            kernel_entry("k_msm_accum (MSMs above 2^18 buckets and the fixed-base MSMs)", acc_ms, acc_n, 96.0 * terms_big, tr("prove2p20/k_msm_accum<Secq>", raw_fetch=True),
+                         madds_big * MADD_PRODUCTS, "terms: the 3 commitment MSMs + L / R of the rounds served by these launches; mixed additions: 13 per term on the "
+                         "fixed-base schedule (c = 20, one bucket set for all windows), %d on the ordinary one" % madds_per_term),
+            kernel_entry("k_msm_accum_fs (fixed-shape pipeline: the mid-size L / R MSMs)", accfs_ms, accfs_n, 96.0 * terms_fs, tr("prove2p20/k_msm_accum_fs<Secq>", raw_fetch=True),
+                         terms_fs * madds_fs * MADD_PRODUCTS, "terms: L / R MSMs of the rounds below 2^18 buckets (incl. the frozen tail's 2 x 16 K-term MSMs per round)"),
             kernel_entry("MSM bucket reduction + aggregation (k_msm_reduce*, k_msm_marginals*, k_msm_window_sums)", agg_ms, agg_n, None, None, None, "latency-bound trees"),
         ]
         # the two accumulate rows share the proof's MSM terms: algorithmic bytes and products for their sum
         acc_all_ms = acc_ms + accfs_ms
-        res["roofline"] = {"bound": "hbm", "kernel": "IPA G/H fold (k_ipa_fold_tab / k_ipa_fold_tab2 [rounds from the tables] + k_ipa_fold_glv + k_ipa_fold_finish + k_ipa_fold_ab), all rounds of one proof",
+        # the dominant kernel group of one proof names the roofline: MSM accumulate (k_msm_accum + k_msm_accum_fs) or the IPA folds
+        acc_dominant = acc_all_ms > fold_ms
+        dom_bytes = 96.0 * (terms_big + terms_fs) if acc_dominant else 576.0 * (N - 1)
+        dom_s = (acc_all_ms if acc_dominant else fold_ms) * 1e-3
+        res["roofline"] = {"bound": "hbm",
+                           "kernel": ("MSM bucket accumulation (k_msm_accum + k_msm_accum_fs), all MSMs of one proof" if acc_dominant else
+                                      "IPA G/H fold (k_ipa_fold_tab / k_ipa_fold_tab2 [rounds from the tables] + k_ipa_fold_glv + k_ipa_fold_finish + k_ipa_fold_ab), all rounds of one proof"),
                            "per": "one 2^%d proof (all launches of the kernel group), run alone after the timed region" % args.logn,
-                           "achieved": 576.0 * (N - 1) / per_proof_s / 1e9,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 576.0 * (N - 1) / per_proof_s / 1e9 / HBM_PEAK_GBS,
+                           "achieved": dom_bytes / dom_s / 1e9,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS,
+                           "dominant_group_ms_per_proof": dom_s * 1e3, "algorithmic_bytes_of_the_group": dom_bytes,
+                           "fold_group": {"algorithmic_bytes": 576.0 * (N - 1), "ms": fold_ms, "hbm_GBps": 576.0 * (N - 1) / per_proof_s / 1e9,
+                                          "hbm_frac": 576.0 * (N - 1) / per_proof_s / 1e9 / HBM_PEAK_GBS},
                            # HBM bytes of all fold launches of ONE proof (same unit as `achieved`), from the committed PMC passes of this shape
                            "traffic": tr(["prove2p20/k_ipa_fold_glv<Secq>", "prove2p20/k_ipa_fold_tab<Secq>", "prove2p20/k_ipa_fold_tab2<Secq>", "prove2p20/k_ipa_fold_finish<Secq>", "prove2p20/k_ipa_fold_ab<Secq>"]),
                            "traffic_note": "traffic above the algorithmic bytes is deliberate here: the table rows streamed by the rounds that come from the tables (34 rows x 64 B per "
@@ -754,7 +794,8 @@ def run_verify(args, rank, world, local):
         else:
             pr = eng.prove_scenario(E.SC_MULTI_RANGE, [nval, nbits, 0], statement_seed(1, i), m_cap=nval + 8)
             distinct.append((E.SC_MULTI_RANGE, [nval, nbits, 0], pr.proof, pr.commitments, pr.publics))
-    total = args.proofs * world
+    strong = bool(getattr(args, "verify_strong", False))
+    total = args.proofs if strong else args.proofs * world      # strong: BASELINE cfg4 as stated — ONE batch of `--proofs` sharded across the GPUs
     lo, hi = P.shard_range(total, rank, world)
     inst_list = [distinct[i % len(distinct)] for i in range(lo, hi)]
     inst = E.pack_instances(inst_list)   # the C ABI's flat arrays, marshalled once (a host in the reference's language owns them already)
@@ -815,6 +856,8 @@ def run_verify(args, rank, world, local):
     host_cpu = cgroup_cpu_delta(cpu0, time.perf_counter() - t0)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     assert ok, "batch verification of valid proofs failed"
+    vfe_dev = sum(e.vfe_stats()[0] for e in engs)
+    vfe_fb = sum(e.vfe_stats()[1] for e in engs)
     for e in engs[1:]:
         e.close()
     # kernel times for the roofline: ONE batch run alone after the timed region (HIP events on the ctx's stream; with batches in
@@ -830,14 +873,17 @@ def run_verify(args, rank, world, local):
     vs_ms, vs_n = eng.kernel_time(5)
     res = {
         "metric": "r1cs_batch_verifies_per_sec", "value": total * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": ("batch_verify of %d k-shuffle proofs per GPU (k = %d: %d randomized multipliers padded to %d, m = %d; benches/r1cs_secq256k1.rs:201-250), %s"
                                 % (args.proofs, shuffle_k, 2 * (shuffle_k - 1), N, m_commit, CURVES[args.curve])) if shuffle_k else
-                               ("cfg4: batch_verify of %d R1CS proofs per GPU, 2^14 constraints each (256 x 64-bit range proofs, m=256), %s"
-                                % (args.proofs, CURVES[args.curve])),
-                   "proofs_per_gpu": args.proofs, "distinct_proofs": len(distinct), "constraints_per_proof": N, "parallelism": "proof-sharded x%d" % world,
+                               ("cfg4: batch_verify of %d R1CS proofs %s, 2^14 constraints each (256 x 64-bit range proofs, m=256), %s"
+                                % (args.proofs, ("in ONE batch sharded across %d GPUs (%d per GPU)" % (world, hi - lo)) if strong else "per GPU", CURVES[args.curve])),
+                   "proofs_per_gpu": hi - lo, "distinct_proofs": len(distinct), "constraints_per_proof": N, "parallelism": "proof-sharded x%d" % world,
                    "batches_in_flight": nfl, "host_cpu_in_timed_region": host_cpu,
+                   "front_end": {"batches_on_the_device": int(vfe_dev), "batches_handed_to_the_host_replay": int(vfe_fb),
+                                 "note": "per-proof codec, transcript replay (Keccak-f / STROBE / ChaCha20 -> Fr::rand) and challenge arithmetic as GPU kernels "
+                                         "(csrc/vfe.hip); ARKBP_VFY_HOST=1 forces the host replay for an A/B"},
                    "stage_ms_per_step": {"whole_call": tms[0] / args.steps * 1e3, "host_replay_overlapped_with_gpu": tms[1] / args.steps * 1e3,
                                          "gpu_drain_and_tail_scaling": tms[2] / args.steps * 1e3, "final_msm": tms[3] / args.steps * 1e3,
                                          "decode": tms[4] / args.steps * 1e3}},
@@ -856,6 +902,23 @@ def run_verify(args, rank, world, local):
         prod_pe = 13.3 if not shuffle_k else 13.5
         products = prod_pe * N * nproofs_per_launch
         tb_ms, tb_n = eng.kernel_time(11)
+        # the per-proof front end on the device (csrc/vfe.hip): one launch each per BATCH (all proofs at once)
+        pt_ms, pt_n = eng.kernel_time(12)
+        sp_ms, sp_n = eng.kernel_time(13)
+        pp_ms, pp_n = eng.kernel_time(14)
+        npts = 11 + 2 * k
+        fe_rows = []
+        if sp_n:
+            msg_bytes = (m_commit + npts) * 65 + 3 * 32
+            fe_rows = [
+                kernel_entry("k_vfe_points (decompression + serialization of every point of the batch)", pt_ms / pt_n, 1,
+                             float(inst.n) * (33 * npts + 64 * m_commit + 64 * (npts + m_commit) + 72 * (npts + m_commit + 3)), None, float(inst.n) * (npts * 385.0 + m_commit * 8.0),
+                             "VALU-bound in the %d square roots per proof (~370 products each)" % npts),
+                kernel_entry("k_vfe_sponge (merlin / STROBE replay + ChaCha20 -> Fr::rand, one lane per proof)", sp_ms / sp_n, 1, float(inst.n) * msg_bytes, None, None,
+                             "a serial chain per proof: ~%d Keccak-f[1600] permutations of ~6 K VALU instructions (no modular products); %d waves for the whole batch — "
+                             "latency-bound, overlaps with other batches' k_vfy_batch" % (msg_bytes // 166 + 2 * (6 + k) + 4, (inst.n + 63) // 64)),
+                kernel_entry("k_vfe_consts + k_vfe_wv + k_vfe_sum2 (inversion, power tables, tail scalars)", pp_ms / pp_n, 3, None, None, float(inst.n) * (520.0 + 3 * k + 9.0 * m_commit), ""),
+            ]
         res["roofline"] = {"bound": "hbm", "kernel": "k_vfy_batch (one launch per block of 512 proofs)", "per": "one launch (%d proofs x %d elements)" % (int(nproofs_per_launch), N),
                            "achieved": 160.0 * N * nproofs_per_launch / avg_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * N * nproofs_per_launch / avg_s / 1e9 / HBM_PEAK_GBS,
@@ -865,7 +928,7 @@ def run_verify(args, rank, world, local):
                            "valu": valu_entry(products, avg_s, "k_vfy_batch is integer-VALU-bound: ~%.1f modular products per (proof, element) against the ceiling derived "
                                               "from the guide's issue rates; SQ counters of this kernel: profiles/r0x_sq_vfy_batch_*.txt" % prod_pe),
                            "kernels": [kernel_entry("k_vfy_batch", vs_ms / vs_n, 1, 160.0 * N * nproofs_per_launch, traffic, products),
-                                       kernel_entry("k_vfy_tables (per-proof split tables)", tb_ms / max(tb_n, 1), 1, None, None, None)]}
+                                       kernel_entry("k_vfy_tables (per-proof split tables)", tb_ms / max(tb_n, 1), 1, None, None, None)] + fe_rows}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         from oracle import pyoracle as O
 
@@ -927,7 +990,7 @@ def run_shuffle_sweep(args, rank, world, local):
     from ark_bulletproofs_amd import engine as E
     from oracle import pyoracle as O
 
-    ks = [1 << i for i in range(1, 11)]
+    ks = getattr(args, "sweep_ks", None) or [1 << i for i in range(1, 11)]
     rows = []
     reps = max(3, args.steps)
     for curve in ([args.curve] if args.sweep_one_curve else [0, 1]):
@@ -959,7 +1022,7 @@ def run_shuffle_sweep(args, rank, world, local):
                             "proof_bytes_identical": True})
             rows.append(row)
         eng.close()
-    big = [r for r in rows if r["k"] == 1024 and r["curve"] == CURVES[args.curve]][0]
+    big = [r for r in rows if r["k"] == max(ks) and r["curve"] == CURVES[args.curve]][0]
     return {"metric": "kshuffle_prove_ms (k = 1024; the whole sweep under \"rows\")", "value": big["gpu_prove_ms"], "unit": "ms", "n_gpus": world, "steps": reps, "warmup": args.warmup,
             "ms_per_step": big["gpu_prove_ms"], "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "the reference's criterion sweep: k-shuffle prove / verify, k = 2..1024, one proof at a time, BulletproofGens::new(2048, 1) "
@@ -986,7 +1049,8 @@ def run_cfg5(args, rank, world, local):
            "ms_per_step": r["ms_per_step"], "ms_per_proof": r["ms_per_step"] / a5.batch, "proofs_per_step": a5.batch,
            "config": {"workload": "cfg5: 2^%d-constraint R1CS prove, Pippenger windows + index-cyclic IPA partitioned across %d GPUs, %s" % (a5.logn, world, CURVES[args.curve]),
                       "verified": r["config"]["verified"], "collectives": r["config"]["collectives"], "first_round_fold_tables": r["config"]["first_round_fold_tables"],
-                      "single_proof_latency_ms": r["config"]["single_proof_latency_ms"], "per_proof_stage_ms": r["config"]["per_proof_stage_ms"],
+                      "in_pipeline_latency_ms": r["config"]["in_pipeline_latency_ms"], "alone_ms_after_rng_head": r["config"]["alone_ms_after_rng_head"],
+                      "rng_head_ms": r["config"]["rng_head_ms"], "per_proof_stage_ms": r["config"]["per_proof_stage_ms"],
                       "pipeline_thread_seconds_per_wall_second": r["config"]["pipeline_thread_seconds_per_wall_second"]},
            "wall_s_including_setup": time.perf_counter() - t0}
     if "roofline" in r:
@@ -994,13 +1058,46 @@ def run_cfg5(args, rank, world, local):
     return out
 
 
+def auto_window(logn, world):
+    """statements alive at once in the prove pipeline: ~0.35 GB of host memory each at 2^20; a quarter of this rank's share of the limit"""
+    per_stmt = 0.35e9 * max(1.0, (1 << logn) / float(1 << 20))
+    return int(max(16, min(128, (mem_limit_bytes() * 0.25 / max(world, 1)) / per_stmt)))
+
+
 def run_headline(args, rank, world, local):
     """both halves of BASELINE.json's metric on one box: prove (top level), then batch verify ("verify"); with N > 1 ranks also the
     north_star's partition of one large proof ("cfg5")"""
+    import copy
+
     res = run_prove(args, rank, world, local)
     ver = run_verify(args, rank, world, local)
     res["metric"] = "r1cs_constraints_proved_per_sec (+ r1cs_batch_verifies_per_sec under \"verify\")"
     res["verify"] = ver
+    res["hbm_spent_on_tables_GB"] = ((res["config"].get("first_round_fold_tables") or {}).get("GB", 0.0)) + ((res["config"].get("fixed_base_msm_tables") or {}).get("GB", 0.0))
+
+    def leg(name, fn, **over):
+        """one more configuration of BASELINE.json in the same line; a failing leg is recorded, the line still comes"""
+        a = copy.copy(args)
+        for k_, v_ in over.items():
+            setattr(a, k_, v_)
+        t_leg = time.perf_counter()
+        try:
+            out = fn(a, rank, world, local)
+            out["wall_s_including_setup"] = time.perf_counter() - t_leg
+            res[name] = out
+        except Exception as exc:
+            res[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:400])}
+            res.setdefault("errors", []).append("%s: %s" % (name, res[name]["error"]))
+
+    if world > 1:
+        # cfg4 in its stated form beside the per-GPU batches above: ONE batch of 4096 proofs sharded across the ranks
+        leg("verify_cfg4_strong", run_verify, verify_strong=True, no_cpu_baseline=True)
+    if world == 1 and not args.headline_only:
+        # the other configurations of BASELINE.json on this one GPU (VERDICT r03: every config in the driver's line)
+        leg("cfg1", run_shuffle_sweep, sweep_ks=[2], sweep_one_curve=True, steps=20, warmup=3)                       # k = 2 shuffle, GPU beside the CPU restatement
+        leg("msm", run_msm, terms=1 << 16, steps=200, warmup=20, shard="terms")                                      # cfg2
+        leg("zorro", run_prove, curve=1, steps=10, warmup=2, tables_off_steps=0, no_cpu_baseline=True)              # cfg3 on the zorro curve
+        leg("prove_2p22", run_prove, logn=22, batch=8, steps=6, warmup=1, tables_off_steps=0, no_cpu_baseline=True, window=auto_window(22, world))  # cfg5's size on ONE GPU (its 8-GPU partition: "cfg5" with --gpus N)
     if world > 1 and args.cfg5_logn > 0:
         res["cfg5"] = guarded_cfg5(args, rank, world, local, res)
         if "error" in res["cfg5"]:
@@ -1066,12 +1163,15 @@ def main():
     ap.add_argument("--verify-wait-us", type=int, default=0, help="verify workload: BP_TUNE_WAIT_SLEEP of the batch ctxs in microseconds (0 = HIP's busy wait)")
     ap.add_argument("--freeze-len", type=int, default=0, help="prove workload: BP_TUNE_IPA_FREEZE_LEN of every ctx (0 = the library's default)")
     ap.add_argument("--tables-off-steps", type=int, default=4, help="prove workload: timed steps of the same pipeline with the precomputed tables released (0 = skip)")
-    ap.add_argument("--fold-table-bits", type=int, default=0, help="window width of those tables (0 = the widest that fits in 3/4 of the free HBM)")
+    ap.add_argument("--fold-table-bits", type=int, default=0, help="window width of those tables (0 = the widest that fits the budget below)")
+    ap.add_argument("--fold-table-budget-gb", type=float, default=125.0, help="HBM the fold tables may take (0 = whatever is free): 125 GB = w 7 at 2^20 on secq256k1, within 2 %% of w 8 at 219 GB")
     ap.add_argument("--terms", type=int, default=1 << 16)
     ap.add_argument("--shard", default="terms", choices=["terms", "windows"],
                     help="multi-GPU partition: msm workload: terms | Pippenger windows; prove workload: replicas (default) | windows = every rank proves the same statements with window-sharded MSMs")
     ap.add_argument("--curve", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="headline workload at --gpus 1: only prove (cfg3) + verify (cfg4), without the cfg1 / cfg2 / zorro / 2^22 legs")
+    ap.add_argument("--verify-strong", action="store_true", help="verify workload with --gpus N: ONE batch of --proofs sharded across the ranks (BASELINE cfg4 as stated) instead of --proofs per GPU")
     ap.add_argument("--strict-exit", action="store_true", help="exit with status 3 (after printing the line) when a leg of the run failed, e.g. the multi-GPU cfg5 leg")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1085,8 +1185,7 @@ def main():
     if args.host_threads <= 0:
         args.host_threads = max(1, int(round(share * 8 / 16)))
     if args.window <= 0:
-        per_stmt = 0.35e9 * max(1.0, (1 << args.logn) / float(1 << 20))
-        args.window = int(max(16, min(128, (mem_limit_bytes() * 0.25 / max(world, 1)) / per_stmt)))
+        args.window = auto_window(args.logn, world)
     if args.build_threads <= 0:
         args.build_threads = max(2, int(round(share * 6 / 16)))
     res = {"msm": run_msm, "prove": run_prove, "verify": run_verify, "headline": run_headline, "shuffle-sweep": run_shuffle_sweep}[args.workload](args, rank, world, local)

@@ -391,7 +391,10 @@ int bp_r1cs_batch_verify_scenarios(bp_ctx* ctx, size_t count, const int* scenari
 #define BP_K_MSM_ACCUM_FS 9 /* k_msm_accum_fs: accumulate of the fixed-shape pipeline (mid-size MSMs) */
 #define BP_K_MSM_AGG 10     /* bucket reduction + aggregation (k_msm_reduce*, k_msm_marginals*, k_msm_window_sums) */
 #define BP_K_VFY_TABLES 11  /* k_vfy_tables */
-#define BP_K_COUNT 12
+#define BP_K_VFE_POINTS 12  /* k_vfe_points: decompression + serialization of a batch's points (device front end of batch verification) */
+#define BP_K_VFE_SPONGE 13  /* k_vfe_sponge: transcript replay + challenge derivation, one lane per proof */
+#define BP_K_VFE_PREPARE 14 /* k_vfe_consts + k_vfe_wv + k_vfe_sum2: challenge arithmetic, parameter blocks, tail scalars */
+#define BP_K_COUNT 15
 int bp_ctx_set_profiling(bp_ctx* ctx, int enabled);
 /* accumulated milliseconds and launch count since the last reset */
 int bp_ctx_kernel_time(bp_ctx* ctx, int which, double* ms_total, uint64_t* launches);
@@ -477,6 +480,14 @@ int bp_debug_vfe_schedule_replay(const uint8_t state203[203], int absorb_commitm
 int bp_debug_vfe_challenges(bp_ctx* ctx, size_t count, const uint8_t* proofs, size_t proof_len, const uint64_t* commit_xy, size_t m, const uint8_t* states203,
                             int shared_state, int absorb_commitments, uint8_t* seeds_out, uint64_t* chal_out, uint32_t* status_out);
 int bp_ctx_vfe_stats(bp_ctx* ctx, uint64_t* device_batches, uint64_t* host_fallbacks);
+/* A ctx WITHOUT a device for sanitizer runs of the host layer on machines with no GPU (tools/sanitize/): only bp_r1cs_batch_verify,
+ * bp_r1cs_batch_verify_scenarios, bp_ctx_set_tuning and bp_ctx_destroy accept it.  They run the complete host side of batch
+ * verification — framing, square roots (on the host here), thread pools, shared recordings, transcript replay (live and lockstep),
+ * template cache and eviction, staging — and skip every kernel, copy and the mega-check: NOTHING IS VERIFIED.  The status is that of
+ * the host replay (format / validation errors in instance order); check_point_xy receives [checksum of everything the host staged,
+ * count, launched groups, 0 ..] so that runs with different thread counts and replay modes can be compared.  gens_capacity: the
+ * generator count the ctx pretends to hold. */
+int bp_debug_ctx_create_hostonly(int curve, size_t gens_capacity, bp_ctx** out);
 /* host only (no GPU): the Fiat-Shamir challenges y z u x w u_1..u_k r of up to eight scenario verifications (flat arrays as in
  * bp_r1cs_batch_verify_scenarios), derived by the per-proof live transcript replay (use_x8 = 0: verify_prepare over the instance's own
  * merlin transcript, src/r1cs/verifier.rs:403-460 + :516-519) or by the lockstep replay of eight same-shaped single-phase instances
