@@ -1096,7 +1096,9 @@ def run_headline(args, rank, world, local):
         # the other configurations of BASELINE.json on this one GPU (every config in the driver's line)
         leg("cfg1", run_shuffle_sweep, sweep_ks=[2], sweep_one_curve=True, steps=20, warmup=3)                       # k = 2 shuffle, GPU beside the CPU restatement
         leg("msm", run_msm, terms=1 << 16, steps=200, warmup=20, shard="terms")                                      # cfg2
-        leg("zorro", run_prove, curve=1, steps=10, warmup=2, tables_off_steps=0, no_cpu_baseline=True)              # cfg3 on the zorro curve
+        # cfg3 on the zorro curve: no endomorphism there, so the fold tables are twice the size per window width and worth more (w = 5 / 84 GB
+        # 14.0 M constraints/s, w = 7 / 238 GB 19.1 M): this leg may take 150 GB (w = 6)
+        leg("zorro", run_prove, curve=1, steps=10, warmup=2, tables_off_steps=0, no_cpu_baseline=True, fold_table_budget_gb=150.0)
         leg("prove_2p22", run_prove, logn=22, batch=8, steps=6, warmup=1, tables_off_steps=0, no_cpu_baseline=True, window=auto_window(22, world))  # cfg5's size on ONE GPU (its 8-GPU partition: "cfg5" with --gpus N)
     if world > 1 and args.cfg5_logn > 0:
         res["cfg5"] = guarded_cfg5(args, rank, world, local, res)
