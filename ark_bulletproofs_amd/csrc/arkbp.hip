@@ -2192,7 +2192,7 @@ static int dbg_verify_challenges(size_t count, const int* scenarios, const uint6
         for (int j = 0; j < 8; j++) { csp[j] = css[j].get(); pfp[j] = &pfs[j]; }
         std::vector<F4> ch[8];
         if (!replay_challenges_x8<C>(csp, pfp, ch)) return 1;
-        for (int j = 0; j < 8; j++) { nchal[j] = ch[j].size(); if (ch[j].size() > 40) return BP_E_ARG; memcpy(out + (size_t)j * 40 * 4, ch[j].data(), ch[j].size() * 32); }
+        for (int j = 0; j < 8; j++) { nchal[j] = ch[j].size(); if (ch[j].size() > 40) return BP_E_ARG; if (!ch[j].empty()) memcpy(out + (size_t)j * 40 * 4, ch[j].data(), ch[j].size() * 32); }
         return BP_OK;
 #else
         return 1;
@@ -2206,7 +2206,7 @@ static int dbg_verify_challenges(size_t count, const int* scenarios, const uint6
         if (rc) return rc;
         if (log.size() > 40) return BP_E_ARG;
         nchal[k] = log.size();
-        memcpy(out + k * 40 * 4, log.data(), log.size() * 32);
+        if (!log.empty()) memcpy(out + k * 40 * 4, log.data(), log.size() * 32);
     }
     return BP_OK;
 }
@@ -2772,7 +2772,7 @@ int bp_host_derive_generators(int curve, int which_H, uint32_t party, size_t cou
     if (curve == 0) host::derive_generators<Secq>(v, which_H ? 'H' : 'G', party, count);
     else if (curve == 1) host::derive_generators<Zorro>(v, which_H ? 'H' : 'G', party, count);
     else return BP_E_ARG;
-    memcpy(out_xy, v.data(), count * 64);
+    if (count) memcpy(out_xy, v.data(), count * 64);
     return BP_OK;
 }
 
@@ -2849,8 +2849,10 @@ int bp_r1cs_prove_scenario(bp_ctx* c, int scenario, const uint64_t* params, cons
     if (rc) return rc;
     if (bytes.size() > *proof_len || io.commitments.size() > m_cap || io.publics.size() > 8) { g_err = "prove: output buffer too small"; return BP_E_ARG; }
     memcpy(proof_out, bytes.data(), bytes.size()); *proof_len = bytes.size();
-    memcpy(commit_xy, io.commitments.data(), io.commitments.size() * 64); *m_out = io.commitments.size();
-    memcpy(publics, io.publics.data(), io.publics.size() * 32); *npub = io.publics.size();
+    if (!io.commitments.empty()) memcpy(commit_xy, io.commitments.data(), io.commitments.size() * 64);   // (memcpy's pointers must be valid even for 0 bytes: UBSan)
+    *m_out = io.commitments.size();
+    if (!io.publics.empty()) memcpy(publics, io.publics.data(), io.publics.size() * 32);
+    *npub = io.publics.size();
     return BP_OK;
 }
 
@@ -2908,8 +2910,8 @@ void bp_stmt_free(bp_stmt* s) { delete s; }
 int bp_stmt_info(bp_stmt* s, uint64_t* commit_xy, size_t m_cap, size_t* m_out, uint64_t* publics, size_t* npub, size_t* multipliers, size_t* constraints) {
     if (!s || !m_out || !npub) return BP_E_ARG;
     if (s->io.commitments.size() > m_cap || s->io.publics.size() > 8) return BP_E_ARG;
-    if (commit_xy) memcpy(commit_xy, s->io.commitments.data(), s->io.commitments.size() * 64);
-    if (publics) memcpy(publics, s->io.publics.data(), s->io.publics.size() * 32);
+    if (commit_xy && !s->io.commitments.empty()) memcpy(commit_xy, s->io.commitments.data(), s->io.commitments.size() * 64);   // (an empty vector's data() may be null: UB for memcpy even with 0 bytes — found by the UBSan build, tests/sanitize)
+    if (publics && !s->io.publics.empty()) memcpy(publics, s->io.publics.data(), s->io.publics.size() * 32);
     *m_out = s->io.commitments.size(); *npub = s->io.publics.size();
     if (multipliers) *multipliers = s->num_vars();
     if (constraints) *constraints = s->num_constraints();

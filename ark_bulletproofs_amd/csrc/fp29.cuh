@@ -12,6 +12,13 @@
 // `fe_load_ark` / `fe_store_ark` convert at the boundary with one Montgomery product each.
 // Device-resident tables keep the R' form, packed into 32 bytes (value < p).
 //
+// Pseudo-Mersenne fields (P::PM: both curves' SCALAR fields, 2^256 - 2^32 - 977 and 2^255 - 19): R' = 1, plain residues; a product
+// is the 81-product schoolbook into eighteen 29-bit limbs, then the high nine limbs are folded onto the low nine with
+// 2^261 mod p (a 38-bit constant: 9 + 9 small multiply-adds), the ~38-bit overflow is folded once more and the last few bits above
+// the modulus width fold with 2^BITS mod p: ~100 v_mad_u64_u32 instead of ~160 for the Montgomery form, same contracts below (the
+// result is < 2^BITS + 2^78: V < 1.000001).  The constants TO29 / FROM29 / R2_29 / ONE29 of such a field are generated for R' = 1
+// (tools/gen_params.py; fe_pm_product below), so everything built on fe_mul / fe_sqr / fe_mul2 and the load / store helpers is representation-blind.
+//
 // Contracts (checked on the CPU by tests/test_fp29_host.py through csrc/fp29_selftest.cpp when
 // ARKBP_CHECK_BOUNDS is defined).  L = largest limb / 2^29, V = value / p:
 //   fe_mul / fe_sqr   in: L(a)*L(b) <= 6, V(a)*V(b) <= 900   out: L = 1, V < V(a)V(b)/32 + 1
@@ -123,12 +130,65 @@ template <class P, int K> ARKBP_HD Fe fe_sub(const Fe& a, const Fe& b) {
 }
 template <class P, int K> ARKBP_HD Fe fe_neg(const Fe& a) { return fe_sub<P, K>(fe_zero<P>(), a); }
 
-// Montgomery product a*b/2^261 mod p, column-wise with one 64-bit accumulator.
+// Pseudo-Mersenne product: col(k, acc) adds the limb products of column k (weight 2^(29k), k = 0..16) to acc.  The HIGH columns
+// 9..16 come first and are carried into nine 29-bit limbs H (the part of the product above 2^261, short of the carry out of column
+// 8, which stays below); the low columns then take H * (2^261 mod p) along in the same accumulator chain — no second pass over the
+// low limbs.  Result: value mod p, < 2^BITS + 2^78, limbs 0..7 < 2^29.
+template <class P, class Col> ARKBP_HD Fe fe_pm_product(Col&& col) {
+    static_assert(P::PM, "pseudo-Mersenne fields only");
+    constexpr u32 c0 = P::PM_C0, c1 = P::PM_C1;       // 2^261 = c0 + c1 * 2^29 (mod p)
+    u32 H[9];
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        col(k, acc);
+        H[k - 9] = (u32)acc & M29;
+        acc >>= 29;
+    }
+    ARKBP_ASSERT(acc < (1ull << 32), "fe_pm_product: product exceeds 18 limbs");
+    H[8] = (u32)acc;
+    Fe r;
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        col(k, acc);
+        acc += (u64)H[k] * c0;
+        if (c1 != 0 && k > 0) acc += (u64)H[k - 1] * c1;
+        r.l[k] = (u32)acc & M29;
+        acc >>= 29;
+    }
+    if (c1 != 0) acc += (u64)H[8] * c1;
+    const u64 o1 = acc;                                // what stands above 2^261 now: < 2^40
+    ARKBP_ASSERT(o1 < (1ull << 41), "fe_pm_product: overflow too large");
+    // last fold: everything above the modulus width — o1 at 2^261 and the top bits of limb 8 (bit BITS = bit BITS - 232 of that limb) —
+    // comes back with 2^BITS mod p = d0 + d1 * 2^29, then ONE full carry pass: limbs 0..7 end strictly below 2^29 (callers multiply
+    // limbs by small constants in 32 bits), limb 8 at most one above 2^(BITS - 232)
+    constexpr int sh = P::BITS - 232;
+    const u64 o = (o1 << (261 - P::BITS)) + (r.l[8] >> sh);
+    r.l[8] &= (1u << sh) - 1u;
+    acc = (u64)r.l[0] + o * P::PM_D0;
+    r.l[0] = (u32)acc & M29; acc >>= 29;
+    acc += (u64)r.l[1] + o * P::PM_D1;
+    r.l[1] = (u32)acc & M29; acc >>= 29;
+    u32 cy = (u32)acc;
+#pragma unroll
+    for (int j = 2; j < 8; j++) { const u32 t = r.l[j] + cy; r.l[j] = t & M29; cy = t >> 29; }
+    r.l[8] += cy;
+    return r;
+}
+
+// Montgomery product a*b/2^261 mod p, column-wise with one 64-bit accumulator.  (Pseudo-Mersenne fields: the plain product a*b mod p.)
 template <class P> ARKBP_HD Fe fe_mul(const Fe& a, const Fe& b) {
 #ifdef ARKBP_CHECK_BOUNDS
     { u64 la = 0, lb = 0; for (int i = 0; i < 9; i++) { if (a.l[i] > la) la = a.l[i]; if (b.l[i] > lb) lb = b.l[i]; }
       ARKBP_ASSERT((unsigned __int128)la * lb <= ((unsigned __int128)6 << 58) + ((unsigned __int128)1 << 40), "fe_mul: L(a)*L(b) > 6"); }
 #endif
+    if constexpr (P::PM) {
+        return fe_pm_product<P>([&](int k, u64& acc) {
+#pragma unroll
+            for (int i = (k < 9 ? 0 : k - 8); i <= (k < 9 ? k : 8); i++) acc += (u64)a.l[i] * b.l[k - i];
+        });
+    }
     u32 m[9];
     Fe t;
     u64 acc = 0;
@@ -165,6 +225,12 @@ template <class P> ARKBP_HD Fe fe_mul2(const Fe& a, const Fe& b, const Fe& c, co
       for (int i = 0; i < 9; i++) { if (a.l[i] > la) la = a.l[i]; if (b.l[i] > lb) lb = b.l[i]; if (c.l[i] > lc) lc = c.l[i]; if (d.l[i] > ld) ld = d.l[i]; }
       ARKBP_ASSERT((unsigned __int128)la * lb + (unsigned __int128)lc * ld <= ((unsigned __int128)6 << 58) + ((unsigned __int128)1 << 41), "fe_mul2: L(a)*L(b) + L(c)*L(d) > 6"); }
 #endif
+    if constexpr (P::PM) {
+        return fe_pm_product<P>([&](int k, u64& acc) {
+#pragma unroll
+            for (int i = (k < 9 ? 0 : k - 8); i <= (k < 9 ? k : 8); i++) { acc += (u64)a.l[i] * b.l[k - i]; acc += (u64)c.l[i] * d.l[k - i]; }
+        });
+    }
     u32 m[9];
     Fe t;
     u64 acc = 0;
@@ -200,6 +266,13 @@ template <class P> ARKBP_HD Fe fe_sqr(const Fe& a) {
 #ifdef ARKBP_CHECK_BOUNDS
     for (int i = 0; i < 9; i++) ARKBP_ASSERT(a.l[i] <= (2u << 29) + 16, "fe_sqr: L(a) > 2");
 #endif
+    if constexpr (P::PM) {
+        return fe_pm_product<P>([&](int k, u64& acc) {
+#pragma unroll
+            for (int i = (k < 9 ? 0 : k - 8); 2 * i < k; i++) acc += (u64)a2[i] * a.l[k - i];
+            if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
+        });
+    }
     Fe t;
     u64 acc = 0;
 #pragma unroll
@@ -311,8 +384,14 @@ ARKBP_HD Fe fe_unpack(const u32 w[8]) {
 template <class P> ARKBP_HD Fe fe_load_ark(const u32 w[8]) { return fe_mul<P>(fe_unpack(w), fe_const<P, P::TO29>()); }
 template <class P> ARKBP_HD void fe_store_ark(u32 w[8], const Fe& a) { fe_pack(w, fe_canon<P>(fe_mul<P>(a, fe_const<P, P::FROM29>()))); }
 // canonical integer words <-> R' form
-template <class P> ARKBP_HD Fe fe_load_canon(const u32 w[8]) { return fe_mul<P>(fe_unpack(w), fe_const<P, P::R2_29>()); }
-template <class P> ARKBP_HD void fe_store_canon(u32 w[8], const Fe& a) { fe_pack(w, fe_canon<P>(fe_mul<P>(a, fe_const<P, P::CANON29>()))); }
+template <class P> ARKBP_HD Fe fe_load_canon(const u32 w[8]) {
+    if constexpr (P::PM) return fe_unpack(w);          // plain residues: the canonical integer IS the representation (any 256-bit value: V < 2.01)
+    else return fe_mul<P>(fe_unpack(w), fe_const<P, P::R2_29>());
+}
+template <class P> ARKBP_HD void fe_store_canon(u32 w[8], const Fe& a) {
+    if constexpr (P::PM) fe_pack(w, fe_canon<P>(a));
+    else fe_pack(w, fe_canon<P>(fe_mul<P>(a, fe_const<P, P::CANON29>())));
+}
 // device-resident packed R' form (value < p)
 template <class P> ARKBP_HD Fe fe_load_dev(const u32 w[8]) { return fe_unpack(w); }
 template <class P> ARKBP_HD void fe_store_dev(u32 w[8], const Fe& a) { fe_pack(w, fe_canon<P>(a)); }
