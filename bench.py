@@ -819,9 +819,11 @@ def run_verify(args, rank, world, local):
     if getattr(args, "verify_wait_us", 0):
         for e in engs:
             e.set_tuning(10, args.verify_wait_us)   # BP_TUNE_WAIT_SLEEP
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         for e in engs:
             e.batch_verify(inst, seed, alpha_skip=lo)
+    t_one = (time.perf_counter() - t_w) / max(1, args.warmup * len(engs))     # one batch alone on the GPU
     barrier(world)
     cpu0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
@@ -834,7 +836,13 @@ def run_verify(args, rank, world, local):
     step_pts = np.zeros((args.steps, 9), dtype=np.uint64)
     nxt, lock, tml = [0], threading.Lock(), []
 
-    def worker(e):
+    # The batches in flight start a fraction of a batch apart.  Started together they stay in lockstep (equal jobs under the GPU's fair
+    # sharing finish together), every batch then stages and uploads its inputs at the same moment, and the GPU idles ~3 ms per round
+    # (kernel trace, profiles/r04_gpu_busy_verify.txt: 79 % busy, every idle gap between a batch's last MSM kernel and the next
+    # batch's first memset); a service's requests do not arrive in phase either.
+    def worker(e, k=0):
+        if k and t_one > 0:
+            time.sleep(min(0.05, t_one) * k / len(engs))
         while True:
             with lock:
                 i = nxt[0]
@@ -846,7 +854,7 @@ def run_verify(args, rank, world, local):
             step_pts[i, 8] = 0 if rc == 0 else 1
             tml.append(tm)
 
-    run_threads([(worker, (e,)) for e in engs])
+    run_threads([(worker, (e, k)) for k, e in enumerate(engs)])
     allp = P.allgather_words(step_pts, device=COLL_DEVICE if world > 1 else None)      # (world, steps, 9)
     for i in range(args.steps):
         ok = ok and not allp[:, i, 8].any() and not E.host_points_sum(args.curve, np.ascontiguousarray(allp[:, i, :8])).any()
@@ -1144,7 +1152,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=["headline", "prove", "verify", "msm", "shuffle-sweep"])
     ap.add_argument("--proofs", type=int, default=4096, help="proofs per GPU per batch (verify workload)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct proofs generated for the verify workload")
-    ap.add_argument("--verify-inflight", type=int, default=4, help="verify workload: batch_verify calls in flight per GPU (own ctx and host pool each; the pools divide the process's CPU quota)")
+    ap.add_argument("--verify-inflight", type=int, default=6, help="verify workload: batch_verify calls in flight per GPU (own ctx and host pool each; the pools divide the process's CPU quota)")
     ap.add_argument("--shuffle-k", type=int, default=0, help="verify workload: batches of k-shuffle proofs (the reference's two-phase benchmark circuit) instead of cfg4's range proofs")
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--cpu-logn", type=int, default=15, help="CPU baseline sample of the prove workload: 2^cpu_logn constraints (about 13 s)")
