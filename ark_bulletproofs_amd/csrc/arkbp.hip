@@ -627,16 +627,24 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
     }
     auto finish_sharded = [&](J4& part) -> int {   // partial point -> sum over the ranks (one 64-byte exchange)
         if (!sharded) return BP_OK;
-        A4 a = G::to_aff(part);
-        uint64_t xy[8]; memcpy(xy, a.x.v, 32); memcpy(xy + 4, a.y.v, 32);
-        if (ctx->nccl) {   // RCCL point-reduce: group addition is not an RCCL reduce op -> all-gather of the 64-byte partials + world-1 host additions
-            std::vector<uint64_t> all((size_t)ctx->shard_world * 8);
-            BPCHK(ctx_native_allgather(ctx, xy, 64, all.data()));
+        if (ctx->nccl) {
+            // RCCL point-reduce: group addition is not an RCCL reduce op -> all-gather of the partials + world-1 host additions.  The
+            // partial travels as it is — Jacobian, 96 bytes — so no rank pays a field inversion per MSM just to ship it;
+            // every rank adds the same points in the same order and normalises its own copy of the sum when the caller asks.
+            uint64_t xyz[12];
+            memcpy(xyz, part.X.v, 32); memcpy(xyz + 4, part.Y.v, 32); memcpy(xyz + 8, part.Z.v, 32);
+            std::vector<uint64_t> all((size_t)ctx->shard_world * 12);
+            BPCHK(ctx_native_allgather(ctx, xyz, 96, all.data()));
             J4 sum = G::inf();
-            for (int r = 0; r < ctx->shard_world; r++) { A4 q; memcpy(q.x.v, &all[(size_t)r * 8], 32); memcpy(q.y.v, &all[(size_t)r * 8 + 4], 32); sum = G::add(sum, G::from_aff(q)); }
+            for (int r = 0; r < ctx->shard_world; r++) {
+                J4 q; memcpy(q.X.v, &all[(size_t)r * 12], 32); memcpy(q.Y.v, &all[(size_t)r * 12 + 4], 32); memcpy(q.Z.v, &all[(size_t)r * 12 + 8], 32);
+                sum = G::add(sum, q);
+            }
             part = sum;
             return BP_OK;
         }
+        A4 a = G::to_aff(part);      // (the callback's contract is an affine point: include/arkbp.h bp_point_reduce_cb)
+        uint64_t xy[8]; memcpy(xy, a.x.v, 32); memcpy(xy + 4, a.y.v, 32);
         const int rc = ctx->shard_cb(ctx->shard_user, xy);
         if (rc) { g_err = "msm: the point-reduce callback failed"; return rc < 0 ? rc : BP_E_ARG; }
         memcpy(a.x.v, xy, 32); memcpy(a.y.v, xy + 4, 32);

@@ -1058,7 +1058,13 @@ def run_cfg5(args, rank, world, local):
            "config": {"workload": "cfg5: 2^%d-constraint R1CS prove, Pippenger windows + index-cyclic IPA partitioned across %d GPUs, %s" % (a5.logn, world, CURVES[args.curve]),
                       "verified": r["config"]["verified"], "collectives": r["config"]["collectives"], "first_round_fold_tables": r["config"]["first_round_fold_tables"],
                       "in_pipeline_latency_ms": r["config"]["in_pipeline_latency_ms"], "alone_ms_after_rng_head": r["config"]["alone_ms_after_rng_head"],
-                      "rng_head_ms": r["config"]["rng_head_ms"], "per_proof_stage_ms": r["config"]["per_proof_stage_ms"],
+                      "rng_head_ms": r["config"]["rng_head_ms"],
+                      "prove_ms_excluding_rng_head": r["config"]["per_proof_stage_ms"].get("prove_total"),
+                      "prove_note": "the TranscriptRng heads of the statements are computed by the pipeline's host threads BEFORE prove() (bp_stmt_precompute_batch, "
+                                    "eight sponges in lockstep): prove_ms_excluding_rng_head is the mean wall time inside prove() with ONE proof partitioned across all "
+                                    "ranks; rng_head_ms (one core, sequential by the reference's construction) is reported beside it, not inside",
+                      "per_rank_table_GB": (r["config"].get("first_round_fold_tables") or {}).get("GB"),
+                      "per_proof_stage_ms": r["config"]["per_proof_stage_ms"],
                       "pipeline_thread_seconds_per_wall_second": r["config"]["pipeline_thread_seconds_per_wall_second"]},
            "wall_s_including_setup": time.perf_counter() - t0}
     if "roofline" in r:

@@ -164,6 +164,77 @@ def test_cfg5_prove_verify_2pow22(curve):
         e.close()
 
 
+def test_cfg5_2pow22_partitioned_across_two_ranks_equals_the_one_rank_proof():
+    """BASELINE cfg5 AS A WHOLE on one GPU: the 2^22-constraint proof through north_star's partition — Pippenger windows of the
+    commitment MSMs and the index-cyclic inner-product argument (2^21 elements per rank, gather at the frozen-tail length) — by two
+    ranks (threads, one Engine each, sharing ONE resident set of generator tables and first-round fold tables), exchanging partial
+    points and the tail vectors through an in-process all-gather.  Both ranks must emit exactly the bytes of the one-rank proof,
+    and the partitioned verifier (window-sharded mega-check) must accept it.  (the partition had run at 2^16, the
+    size on one rank — never both.)"""
+    import threading
+
+    import ark_bulletproofs_amd as A
+    from ark_bulletproofs_amd import engine as E
+    from ark_bulletproofs_amd import parallel as P
+
+    N, world, cv = 1 << 22, 2, 0
+    seed = bytes([9]) * 32
+    single = A.Engine(curve=cv)
+    try:
+        single.gens_derive(N)
+        st = E.Statement(cv, E.SC_SQUARE_CHAIN, [N, 0], seed)
+        commits, pubs, nm, _ = st.info(m_cap=8)
+        assert nm == N
+        ref, _ = st.prove(single)
+        st.free()
+        assert single.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], ref, commits, pubs) == 0
+        single.gens_fold_tables(N // 2, window_bits=4)          # the ranks index the same tables with a stride
+        bar = threading.Barrier(world)
+        slots, out, errors = [None] * world, [None] * world, []
+        gathers = [[0, 0] for _ in range(world)]                  # [64-byte point reduces, vector gathers]
+
+        def run(rank):
+            try:
+                e = A.Engine(curve=cv)
+                e.share_gens_from(single)
+
+                def allgather(arr):
+                    gathers[rank][1 if np.asarray(arr).size > 8 else 0] += 1
+                    slots[rank] = np.array(arr, copy=True)
+                    bar.wait()
+                    res = np.stack(slots)
+                    bar.wait()
+                    return res
+
+                P.enable_window_sharding(e, cv, E.host_points_sum, rank, world, allgather=allgather)
+                s2 = E.Statement(cv, E.SC_SQUARE_CHAIN, [N, 0], seed)
+                proof, _ = s2.prove(e)
+                s2.free()
+                n_prove = list(gathers[rank])
+                rc = e.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], proof, commits, pubs)
+                out[rank] = (proof, rc, n_prove)
+                P.enable_window_sharding(e, cv, E.host_points_sum, 0, 1)
+                e.close()
+            except Exception as ex:   # noqa: BLE001
+                errors.append(ex)
+                bar.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        for r in range(world):
+            proof, rc, (n_pts, n_vec) = out[r]
+            assert proof == ref, "rank %d's proof differs from the one-rank proof" % r
+            assert rc == 0
+            assert n_vec == 1, "the index-cyclic inner-product argument was not taken (vector gathers: %d)" % n_vec
+            assert n_pts >= 6 + 2 * 9, "too few point reduces for a partitioned proof: %d" % n_pts
+    finally:
+        single.close()
+
+
 def test_batch_of_600_distinct_statements(eng):
     """one template per STRUCTURE, not per statement: 600 distinct-witness proofs (square chains with 600 different public outputs,
     range proofs of 64 different values) in one batch — more than the template cache (64) and more than a 512-block"""
