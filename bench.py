@@ -269,8 +269,8 @@ def pmc_traffic(keys, applicable, fname, field="largest", raw_fetch=False):
     if not applicable:
         return None
     try:
-        f3 = os.path.join(ROOT, "profiles", fname.replace("r02_", "r03_"))
-        d = json.load(open(f3 if os.path.exists(f3) else os.path.join(ROOT, "profiles", fname)))
+        cands = [os.path.join(ROOT, "profiles", fname.replace("r02_", r)) for r in ("r04_", "r03_", "r02_")]   # the newest round's passes of this workload
+        d = json.load(open(next(c for c in cands if os.path.exists(c))))
         tot, found = 0.0, 0
         for k in ([keys] if isinstance(keys, str) else keys):
             # (a kernel the profiled configuration did not launch contributes nothing; "name<Curve>" also stands for the
@@ -920,9 +920,11 @@ def run_verify(args, rank, world, local):
             msg_bytes = (m_commit + npts) * 65 + 3 * 32
             fe_rows = [
                 kernel_entry("k_vfe_points (decompression + serialization of every point of the batch)", pt_ms / pt_n, 1,
-                             float(inst.n) * (33 * npts + 64 * m_commit + 64 * (npts + m_commit) + 72 * (npts + m_commit + 3)), None, float(inst.n) * (npts * 385.0 + m_commit * 8.0),
+                             float(inst.n) * (33 * npts + 64 * m_commit + 64 * (npts + m_commit) + 72 * (npts + m_commit + 3)),
+                             pmc_traffic("verify4096/vfe::k_vfe_points<Secq>", cfg4, "r02_pmc_verify4096_summary.json", raw_fetch=True), float(inst.n) * (npts * 385.0 + m_commit * 8.0),
                              "VALU-bound in the %d square roots per proof (~370 products each)" % npts),
-                kernel_entry("k_vfe_sponge (merlin / STROBE replay + ChaCha20 -> Fr::rand, one lane per proof)", sp_ms / sp_n, 1, float(inst.n) * msg_bytes, None, None,
+                kernel_entry("k_vfe_sponge (merlin / STROBE replay + ChaCha20 -> Fr::rand, one lane per proof)", sp_ms / sp_n, 1, float(inst.n) * msg_bytes,
+                             pmc_traffic("verify4096/vfe::k_vfe_sponge<Secq>", cfg4, "r02_pmc_verify4096_summary.json"), None,
                              "a serial chain per proof: ~%d Keccak-f[1600] permutations of ~6 K VALU instructions (no modular products); %d waves for the whole batch — "
                              "latency-bound, overlaps with other batches' k_vfy_batch" % (msg_bytes // 166 + 2 * (6 + k) + 4, (inst.n + 63) // 64)),
                 kernel_entry("k_vfe_consts + k_vfe_wv + k_vfe_sum2 (inversion, power tables, tail scalars)", pp_ms / pp_n, 3, None, None, float(inst.n) * (520.0 + 3 * k + 9.0 * m_commit), ""),
