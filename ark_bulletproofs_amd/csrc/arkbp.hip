@@ -249,6 +249,7 @@ struct bp_ctx {
     size_t h_vfe_cap = 0;
     std::map<std::string, std::shared_ptr<void>> vfe_classes;   // (shared recording, m, k, transcript position) -> VfeClassDev<C>
     bool tune_vfy_device = true;              // BP_TUNE_VFY_DEVICE
+    uint64_t fb_runs = 0, fb_runs_sharded = 0; // fixed-base MSMs completed on this ctx / of those, on a rank's share of the terms of a sharded proof
     uint64_t vfe_batches = 0, vfe_fallbacks = 0;                 // batches the device front end completed / handed to the host replay
     void* h_vstage[2] = {nullptr, nullptr};   // pinned staging halves of the batch-verify pipeline
     size_t h_vstage_cap[2] = {0, 0};
@@ -605,6 +606,36 @@ template <class C> static int msm_run_fs_glv(bp_ctx* ctx, const BaseSegs& segs_i
     }
 }
 
+// A rank's partial point -> the sum over the ranks of a sharded ctx (one small exchange): RCCL all-gather of the Jacobian partials
+// inside the library, or the host's point-reduce callback.
+template <class C> static int shard_point_reduce(bp_ctx* ctx, J4& part) {
+    typedef host::Grp<C> G;
+    if (ctx->nccl) {
+        // RCCL point-reduce: group addition is not an RCCL reduce op -> all-gather of the partials + world-1 host additions.  The
+        // partial travels as it is — Jacobian, 96 bytes — so no rank pays a field inversion per MSM just to ship it;
+        // every rank adds the same points in the same order and normalises its own copy of the sum when the caller asks.
+        uint64_t xyz[12];
+        memcpy(xyz, part.X.v, 32); memcpy(xyz + 4, part.Y.v, 32); memcpy(xyz + 8, part.Z.v, 32);
+        std::vector<uint64_t> all((size_t)ctx->shard_world * 12);
+        BPCHK(ctx_native_allgather(ctx, xyz, 96, all.data()));
+        J4 sum = G::inf();
+        for (int r = 0; r < ctx->shard_world; r++) {
+            J4 q; memcpy(q.X.v, &all[(size_t)r * 12], 32); memcpy(q.Y.v, &all[(size_t)r * 12 + 4], 32); memcpy(q.Z.v, &all[(size_t)r * 12 + 8], 32);
+            sum = G::add(sum, q);
+        }
+        part = sum;
+        return BP_OK;
+    }
+    if (!ctx->shard_cb) { g_err = "sharded mode: no point-reduce installed"; return BP_E_ARG; }
+    A4 a = G::to_aff(part);      // (the callback's contract is an affine point: include/arkbp.h bp_point_reduce_cb)
+    uint64_t xy[8]; memcpy(xy, a.x.v, 32); memcpy(xy + 4, a.y.v, 32);
+    const int rc = ctx->shard_cb(ctx->shard_user, xy);
+    if (rc) { g_err = "msm: the point-reduce callback failed"; return rc < 0 ? rc : BP_E_ARG; }
+    memcpy(a.x.v, xy, 32); memcpy(a.y.v, xy + 4, 32);
+    part = G::from_aff(a);
+    return BP_OK;
+}
+
 template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u32* d_scalars_one, size_t n, int scalars_mont, J4& result,
                                       int w_lo = 0, int w_hi = -1 /* window range for multi-GPU window sharding; default all */,
                                       int shard_mode = -1 /* -1: the ctx's mode (window partition + reduce when world > 1); 0: none (replicated);
@@ -625,31 +656,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
         w_lo = r * base + std::min(r, rem);
         w_hi = w_lo + base + (r < rem ? 1 : 0);
     }
-    auto finish_sharded = [&](J4& part) -> int {   // partial point -> sum over the ranks (one 64-byte exchange)
+    auto finish_sharded = [&](J4& part) -> int {   // partial point -> sum over the ranks (one small exchange)
         if (!sharded) return BP_OK;
-        if (ctx->nccl) {
-            // RCCL point-reduce: group addition is not an RCCL reduce op -> all-gather of the partials + world-1 host additions.  The
-            // partial travels as it is — Jacobian, 96 bytes — so no rank pays a field inversion per MSM just to ship it;
-            // every rank adds the same points in the same order and normalises its own copy of the sum when the caller asks.
-            uint64_t xyz[12];
-            memcpy(xyz, part.X.v, 32); memcpy(xyz + 4, part.Y.v, 32); memcpy(xyz + 8, part.Z.v, 32);
-            std::vector<uint64_t> all((size_t)ctx->shard_world * 12);
-            BPCHK(ctx_native_allgather(ctx, xyz, 96, all.data()));
-            J4 sum = G::inf();
-            for (int r = 0; r < ctx->shard_world; r++) {
-                J4 q; memcpy(q.X.v, &all[(size_t)r * 12], 32); memcpy(q.Y.v, &all[(size_t)r * 12 + 4], 32); memcpy(q.Z.v, &all[(size_t)r * 12 + 8], 32);
-                sum = G::add(sum, q);
-            }
-            part = sum;
-            return BP_OK;
-        }
-        A4 a = G::to_aff(part);      // (the callback's contract is an affine point: include/arkbp.h bp_point_reduce_cb)
-        uint64_t xy[8]; memcpy(xy, a.x.v, 32); memcpy(xy + 4, a.y.v, 32);
-        const int rc = ctx->shard_cb(ctx->shard_user, xy);
-        if (rc) { g_err = "msm: the point-reduce callback failed"; return rc < 0 ? rc : BP_E_ARG; }
-        memcpy(a.x.v, xy, 32); memcpy(a.y.v, xy + 4, 32);
-        part = G::from_aff(a);
-        return BP_OK;
+        return shard_point_reduce<C>(ctx, part);
     };
     if constexpr (C::HAS_GLV) {
         // mid-size MSMs on a curve with the endomorphism: the fixed-shape pipeline over GLV-split scalars (half the windows)
@@ -955,7 +964,7 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
 // ---- fixed-base MSM over the generator tables (msm.cuh 1c) -----------------------------------------------------------------
 static constexpr u32 FB_ROWS = 65;   // rows at bit positions 0, 4, 8, .., 256: any window width c that is a multiple of 4 finds its rows (the last one serves the carry window)
 // A run of generator-table bases of a fixed-base MSM: which table (0 = G, 1 = H, 2 = PedersenGens {B, B_blinding}), first index, count
-struct FbRun { int table; size_t first, count; };
+struct FbRun { int table; size_t first, count; size_t stride = 1; };   // stride: base j of the run is table[first + j * stride] (an index-cyclic slice)
 template <class C> static int fb_tables_build(bp_ctx* ctx, size_t cap) {
     hipStream_t st = ctx->stream;
     if (cap == 0 || cap > ctx->gens_cap) { g_err = "msm tables: more bases than installed generators"; return BP_E_GENS_LENGTH; }
@@ -989,21 +998,26 @@ template <class C> static int fb_tables_build(bp_ctx* ctx, size_t cap) {
 // (no tables, a run beyond them, skewed scalars overflowing a bin region, window-sharded ctx): the caller then runs the
 // ordinary MSM over the same bases.
 template <class C>
-static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSegs& ssegs, size_t n, int scalars_mont, J4& result, bool& done) {
+static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSegs& ssegs, size_t n, int scalars_mont, J4& result, bool& done,
+                         int shard_mode = -1 /* on a sharded ctx: 2 = the runs are THIS RANK'S share of the terms: all windows here, then the point-reduce
+                                                 (the single-GPU schedule at 1/world of the terms); anything else: step aside */) {
     typedef host::Grp<C> G;
     done = false;
+    const bool reduce_after = ctx->shard_world > 1 && shard_mode == 2;
+    if (ctx->shard_world > 1 && !reduce_after) return BP_OK;
     static const bool off = getenv("ARKBP_MSM_NOFIXED") != nullptr;   // A/B switch
     // pays from ~2^20 terms (2^21: all kernels 5.6 -> 4.5 ms; at 2^19 and below the single latency-bound aggregation pass costs more
     // than the saved additions: tools/exp_msm_gens.py)
-    if (off || !ctx->fb_cap || ctx->shard_world > 1 || n < std::max<size_t>(ctx->tune_msm_fixed_min, 4096) || n >= ((size_t)1 << 24) || nruns > MSM_MAXSEG) return BP_OK;
+    if (off || !ctx->fb_cap || n < std::max<size_t>(ctx->tune_msm_fixed_min, 4096) || n >= ((size_t)1 << 24) || nruns > MSM_MAXSEG) return BP_OK;
     BaseSegs segs; memset(&segs, 0, sizeof segs);
     u32 at = 0;
     for (int k = 0; k < nruns; k++) {
         const size_t cap = runs[k].table == 2 ? 2 : ctx->fb_cap;
-        if (runs[k].first + runs[k].count > cap) return BP_OK;
+        if (runs[k].count && runs[k].first + (runs[k].count - 1) * runs[k].stride + 1 > cap) return BP_OK;
         const DevBuf& tb = runs[k].table == 0 ? ctx->fb_G : runs[k].table == 1 ? ctx->fb_H : ctx->fb_pc;
         segs.ptr[k] = (const u32*)tb.p + runs[k].first * 16;
         segs.row_words[k] = (u64)cap * 16;
+        segs.stride[k] = (u32)runs[k].stride;
         segs.start[k] = at; at += (u32)runs[k].count;
     }
     segs.start[nruns] = at; segs.nseg = nruns;
@@ -1079,7 +1093,7 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     }
     result = G::inf();
     done = true;
-    if (tot[0] == 0) { total.stop(); return BP_OK; }
+    if (tot[0] == 0) { total.stop(); return reduce_after ? shard_point_reduce<C>(ctx, result) : BP_OK; }
     const u32 maxcnt = tot[NL];
     int K = 1;
     { u64 capl = (u64)1 << chl; while (capl < maxcnt) { capl <<= chl; K++; } }
@@ -1110,7 +1124,9 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     const u64* T = (const u64*)ctx->h_T;
     J4 pnt; memcpy(pnt.X.v, T, 32); memcpy(pnt.Y.v, T + 4, 32); memcpy(pnt.Z.v, T + 8, 32);
     if (!pnt.Z.is_zero()) result = pnt;   // no Horner tail: the rows already carry the powers of two
-    return BP_OK;
+    ctx->fb_runs++;
+    if (reduce_after) ctx->fb_runs_sharded++;
+    return reduce_after ? shard_point_reduce<C>(ctx, result) : BP_OK;
 }
 
 // MSM over the resident generator tables (no base upload): bases = G[off..off+n) (if use_G) || H[off..off+n) (if use_H) || extras
@@ -1598,9 +1614,29 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
     const u32* Hb = s.d_H_in ? s.d_H_in : s.d_H;
     sg.ptr[0] = Gb + n * 16; sg.ptr[1] = Hb; sg.ptr[2] = s.d_Q;
     J4 Lj, Rj;
-    BPCHK(msm_run<C>(ctx, sg, sL, 2 * n + 1, 0, Lj, 0, -1, s.msm_mode));
+    // Index-cyclic sharded prover, round 1: this rank's terms are ITS slice of the generator tables (bases first + j * world) — with
+    // fixed-base rows installed they keep the single-GPU schedule, reading the rows with a stride (Q = qw * B rides along as a row of
+    // the Pedersen table with this rank's partial inner product).  A rank whose scalars do not go through it runs the ordinary MSM
+    // over its compact copy: either way one point-reduce per L and per R.
+    const bool cyc_fixed = s.first && s.msm_mode == 2 && s.gens_stride > 1 && s.have_qw && ctx->fb_cap;
+    bool dl = false, dr = false;
+    if (cyc_fixed) {
+        ScalSegs ss; memset(&ss, 0, sizeof ss);
+        ss.nseg = 2; ss.ptr[0] = sL; ss.start[0] = 0; ss.start[1] = (u32)(2 * n); ss.ptr[1] = sL + (2 * n + 1) * 8; ss.start[2] = (u32)(2 * n + 1);
+        const size_t f0 = s.gens_first, sd = s.gens_stride;
+        FbRun rl[3] = {{0, f0 + n * sd, n, sd}, {1, f0, n, sd}, {2, 0, 1}};
+        BPCHK(msm_fixed_run<C>(ctx, rl, 3, ss, 2 * n + 1, 0, Lj, dl, 2));
+    }
+    if (!dl) BPCHK(msm_run<C>(ctx, sg, sL, 2 * n + 1, 0, Lj, 0, -1, s.msm_mode));
     sg.ptr[0] = Gb; sg.ptr[1] = Hb + n * 16;
-    BPCHK(msm_run<C>(ctx, sg, sR, 2 * n + 1, 0, Rj, 0, -1, s.msm_mode));
+    if (cyc_fixed) {
+        ScalSegs ss; memset(&ss, 0, sizeof ss);
+        ss.nseg = 2; ss.ptr[0] = sR; ss.start[0] = 0; ss.start[1] = (u32)(2 * n); ss.ptr[1] = sR + (2 * n + 1) * 8; ss.start[2] = (u32)(2 * n + 1);
+        const size_t f0 = s.gens_first, sd = s.gens_stride;
+        FbRun rr[3] = {{0, f0, n, sd}, {1, f0 + n * sd, n, sd}, {2, 0, 1}};
+        BPCHK(msm_fixed_run<C>(ctx, rr, 3, ss, 2 * n + 1, 0, Rj, dr, 2));
+    }
+    if (!dr) BPCHK(msm_run<C>(ctx, sg, sR, 2 * n + 1, 0, Rj, 0, -1, s.msm_mode));
     A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
     memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
     memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
@@ -1783,7 +1819,7 @@ struct Blk64 { uint4 a, b, c, d; };
 template <class C>
 static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, const u32* d_Gtab, const u32* d_Htab, const u32* d_a, const u32* d_b,
                              size_t N, const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4],
-                             const F4* gf_halves, const F4* rho_pw, const u32* d_rho_pow) {
+                             const F4* gf_halves, const F4* rho_pw, const u32* d_rho_pow, const F4* qw = nullptr /* Q = qw * B (the R1CS prover's Q) */) {
     typedef typename C::Fr FrP;
     typedef host::Fld<FrP> S;
     hipStream_t st = ctx->stream;
@@ -1814,6 +1850,7 @@ static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const
                            ctx->cyc_b.as<u32>(), n_loc, gf_halves, geo ? rho_loc : nullptr, geo ? d_rho_pow + (size_t)w * 8 : nullptr, false));
     s.msm_mode = 2;
     s.gens_first = (u32)r; s.gens_stride = (u32)W;
+    if (qw) { s.qw = *qw; s.have_qw = true; }
     F4 rho_r = S::one(), rho_mr = S::one();   // rho^rank, rho^-rank
     if (geo) for (int k = 0; k < w; k++) if ((r >> k) & 1) { rho_r = S::mul(rho_r, rho_pw[32 + k]); rho_mr = S::mul(rho_mr, rho_pw[k]); }
     s.geo_k0 = rho_r; s.have_k0 = geo;
@@ -3217,6 +3254,12 @@ int bp_debug_verify_challenges(int curve, size_t count, const int* scenarios, co
     if (!count || count > 8 || !scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !publics || !npubs || !out || !nchal) return BP_E_ARG;
     return curve == 0 ? dbg_verify_challenges<Secq>(count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, use_x8, out, nchal)
                       : dbg_verify_challenges<Zorro>(count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, use_x8, out, nchal);
+}
+int bp_ctx_msm_stats(bp_ctx* c, uint64_t* fixed_base_runs, uint64_t* fixed_base_runs_sharded) {
+    if (!c) return BP_E_ARG;
+    if (fixed_base_runs) *fixed_base_runs = c->fb_runs;
+    if (fixed_base_runs_sharded) *fixed_base_runs_sharded = c->fb_runs_sharded;
+    return BP_OK;
 }
 int bp_ctx_vfe_stats(bp_ctx* c, uint64_t* device_batches, uint64_t* host_fallbacks) {
     if (!c) return BP_E_ARG;

@@ -49,6 +49,9 @@ struct BaseSegs {
     u64 row_words[MSM_MAXSEG];
     // GLV mode (glv_split below): an entry's term field is 2 * term + half; half 1 stands for phi(base) = (beta * x, y)
     u32 glv;
+    // element stride of a segment in points (0 = 1): an index-cyclic slice of a generator table read in place (term j of the
+    // segment is base first + j * stride — the sharded prover's rank r owns the bases r, r + world, ..)
+    u32 stride[MSM_MAXSEG];
 };
 __device__ __forceinline__ const u32* seg_base_ptr(const BaseSegs& s, u32 idx) {
     u32 w = 0;
@@ -57,7 +60,8 @@ __device__ __forceinline__ const u32* seg_base_ptr(const BaseSegs& s, u32 idx) {
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MSM_MAXSEG; j++) k += (j < s.nseg && idx >= s.start[j]) ? 1 : 0;
-    return s.ptr[k] + (size_t)(idx - s.start[k]) * 16 + (size_t)(w * s.fixed_c4) * s.row_words[k];
+    const u32 sd = s.stride[k] ? s.stride[k] : 1u;
+    return s.ptr[k] + (size_t)(idx - s.start[k]) * sd * 16 + (size_t)(w * s.fixed_c4) * s.row_words[k];
 }
 
 // The scalar vector of an MSM, likewise: up to MSM_MAXSEG device-resident runs (e.g. blinding || a_L || a_R of a commitment,

@@ -967,3 +967,12 @@ def debug_verify_challenges(curve, instances, use_x8):
         return None
     check(rc, "bp_debug_verify_challenges")
     return [out[j, : nch[j]].copy() for j in range(pk.n)]
+
+
+def _msm_stats(self):
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    check(lib().bp_ctx_msm_stats(self.ctx, C.byref(a), C.byref(b)), "bp_ctx_msm_stats")
+    return a.value, b.value
+
+
+Engine.msm_stats = _msm_stats

@@ -480,6 +480,9 @@ int bp_debug_vfe_schedule_replay(const uint8_t state203[203], int absorb_commitm
 int bp_debug_vfe_challenges(bp_ctx* ctx, size_t count, const uint8_t* proofs, size_t proof_len, const uint64_t* commit_xy, size_t m, const uint8_t* states203,
                             int shared_state, int absorb_commitments, uint8_t* seeds_out, uint64_t* chal_out, uint32_t* status_out);
 int bp_ctx_vfe_stats(bp_ctx* ctx, uint64_t* device_batches, uint64_t* host_fallbacks);
+/* MSMs over the generator tables that took the fixed-base schedule (bp_gens_msm_tables) on this ctx, and how many of those ran on a
+ * rank's share of the terms of a sharded proof (blocks of a commitment's terms, the strided slice of the first IPA round) */
+int bp_ctx_msm_stats(bp_ctx* ctx, uint64_t* fixed_base_runs, uint64_t* fixed_base_runs_sharded);
 /* A ctx WITHOUT a device for sanitizer runs of the host layer on machines with no GPU (tools/sanitize/): only bp_r1cs_batch_verify,
  * bp_r1cs_batch_verify_scenarios, bp_ctx_set_tuning and bp_ctx_destroy accept it.  They run the complete host side of batch
  * verification — framing, square roots (on the host here), thread pools, shared recordings, transcript replay (live and lockstep),

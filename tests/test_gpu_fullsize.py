@@ -189,6 +189,7 @@ def test_cfg5_2pow22_partitioned_across_two_ranks_equals_the_one_rank_proof():
         st.free()
         assert single.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], ref, commits, pubs) == 0
         single.gens_fold_tables(N // 2, window_bits=4)          # the ranks index the same tables with a stride
+        single.gens_msm_tables(N)                               # fixed-base rows: per-rank blocks of the commitments, strided rows in round 1
         bar = threading.Barrier(world)
         slots, out, errors = [None] * world, [None] * world, []
         gathers = [[0, 0] for _ in range(world)]                  # [64-byte point reduces, vector gathers]
@@ -211,8 +212,9 @@ def test_cfg5_2pow22_partitioned_across_two_ranks_equals_the_one_rank_proof():
                 proof, _ = s2.prove(e)
                 s2.free()
                 n_prove = list(gathers[rank])
+                fb = e.msm_stats()[1]
                 rc = e.verify_scenario(E.SC_SQUARE_CHAIN, [N, 0], proof, commits, pubs)
-                out[rank] = (proof, rc, n_prove)
+                out[rank] = (proof, rc, n_prove, fb)
                 P.enable_window_sharding(e, cv, E.host_points_sum, 0, 1)
                 e.close()
             except Exception as ex:   # noqa: BLE001
@@ -226,7 +228,8 @@ def test_cfg5_2pow22_partitioned_across_two_ranks_equals_the_one_rank_proof():
             t.join()
         assert not errors, errors
         for r in range(world):
-            proof, rc, (n_pts, n_vec) = out[r]
+            proof, rc, (n_pts, n_vec), fb = out[r]
+            assert fb >= 5, "the sharded prover stepped back from the fixed-base MSM schedule (%d runs on rank %d)" % (fb, r)
             assert proof == ref, "rank %d's proof differs from the one-rank proof" % r
             assert rc == 0
             assert n_vec == 1, "the index-cyclic inner-product argument was not taken (vector gathers: %d)" % n_vec

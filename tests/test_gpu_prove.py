@@ -204,8 +204,9 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
     single = A.Engine(curve=cv)
     single.gens_derive(N)
     refs = [single.prove_scenario(sc, prm, SEED, m_cap=N + 16) for sc, prm in cases]
-    # the ranks share the first-round fold tables and the fixed-base MSM rows too (the cyclic slices index them with a stride;
-    # the fixed-base MSMs step aside in sharded mode): same proofs
+    # the ranks share the first-round fold tables and the fixed-base MSM rows too: the cyclic slices index both with a stride, the
+    # commitments take the fixed-base schedule over per-rank blocks of the terms (round 4: the sharded prover keeps the single-GPU
+    # MSM algorithm; BP_TUNE_MSM_FIXED_MIN lowered on every rank so that 2^16 reaches it): same proofs
     single.gens_fold_tables(N // 2, window_bits=4)
     single.gens_msm_tables(N)
     single.set_tuning(5, 4096)
@@ -230,17 +231,20 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
                 return res
 
             P.enable_window_sharding(e, cv, E.host_points_sum, rank, world, allgather=allgather)
+            e.set_tuning(5, 4096)       # BP_TUNE_MSM_FIXED_MIN
             got = []
             for (sc, prm) in cases:
                 pr = e.prove_scenario(sc, prm, SEED, m_cap=N + 16)
                 got.append((pr.proof, e.verify_scenario(sc, prm, pr.proof, pr.commitments, pr.publics)))
             out[rank] = got
+            fb_sharded[rank] = e.msm_stats()[1]
             P.enable_window_sharding(e, cv, E.host_points_sum, 0, 1)
             e.close()
         except Exception as ex:
             errors.append(ex)
             bar.abort()
 
+    fb_sharded = [0] * world
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
@@ -251,6 +255,8 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
         for (proof, rc), ref in zip(out[r], refs):
             assert proof == ref.proof and rc == 0
         assert big_gathers[r] == len(cases), "the index-cyclic IPA path was not taken"
+        # the square chain's three commitments + L and R of its first round ran as fixed-base MSMs on this rank's share of the terms
+        assert fb_sharded[r] >= 5, "the sharded prover stepped back from the fixed-base schedule (%d runs)" % fb_sharded[r]
     single.close()
 
 
