@@ -1003,17 +1003,19 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
                                                  (the single-GPU schedule at 1/world of the terms); anything else: step aside */) {
     typedef host::Grp<C> G;
     done = false;
+    static const bool fbtrace = getenv("ARKBP_FB_TRACE") != nullptr;
+#define FBX(k) do { if (fbtrace) fprintf(stderr, "[fixed-base] declined at exit %d (n = %zu, runs = %d, world = %d, mode = %d)\n", k, n, nruns, ctx->shard_world, shard_mode); return BP_OK; } while (0)
     const bool reduce_after = ctx->shard_world > 1 && shard_mode == 2;
-    if (ctx->shard_world > 1 && !reduce_after) return BP_OK;
+    if (ctx->shard_world > 1 && !reduce_after) FBX(1);
     static const bool off = getenv("ARKBP_MSM_NOFIXED") != nullptr;   // A/B switch
     // pays from ~2^20 terms (2^21: all kernels 5.6 -> 4.5 ms; at 2^19 and below the single latency-bound aggregation pass costs more
     // than the saved additions: tools/exp_msm_gens.py)
-    if (off || !ctx->fb_cap || n < std::max<size_t>(ctx->tune_msm_fixed_min, 4096) || n >= ((size_t)1 << 24) || nruns > MSM_MAXSEG) return BP_OK;
+    if (off || !ctx->fb_cap || n < std::max<size_t>(ctx->tune_msm_fixed_min, 4096) || n >= ((size_t)1 << 24) || nruns > MSM_MAXSEG) FBX(2);
     BaseSegs segs; memset(&segs, 0, sizeof segs);
     u32 at = 0;
     for (int k = 0; k < nruns; k++) {
         const size_t cap = runs[k].table == 2 ? 2 : ctx->fb_cap;
-        if (runs[k].count && runs[k].first + (runs[k].count - 1) * runs[k].stride + 1 > cap) return BP_OK;
+        if (runs[k].count && runs[k].first + (runs[k].count - 1) * runs[k].stride + 1 > cap) FBX(3);
         const DevBuf& tb = runs[k].table == 0 ? ctx->fb_G : runs[k].table == 1 ? ctx->fb_H : ctx->fb_pc;
         segs.ptr[k] = (const u32*)tb.p + runs[k].first * 16;
         segs.row_words[k] = (u64)cap * 16;
@@ -1034,7 +1036,7 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     static const int c_env = getenv("ARKBP_MSM_FIXED_C") ? atoi(getenv("ARKBP_MSM_FIXED_C")) : 0;
     if (c_env >= 8 && c_env <= 24 && c_env % 4 == 0) bc = c_env;
     MsmPlan pl; pl.c = bc; pl.W = bits / bc + 1; pl.NB = 1 << (bc - 1); pl.B = (u32)pl.NB; pl.n = (u32)n; pl.w_lo = 0; pl.w_hi = pl.W;
-    if ((u32)(pl.W - 1) * (u32)(bc / 4) >= FB_ROWS) return BP_OK;
+    if ((u32)(pl.W - 1) * (u32)(bc / 4) >= FB_ROWS) FBX(4);
     u32 tbits = 1; while (((size_t)1 << tbits) < n) tbits++;   // (term indices are < n: n itself need not fit)
     u32 wbits = 1; while ((1 << wbits) < pl.W) wbits++;
     const u32 vbits = tbits + wbits;
@@ -1044,14 +1046,14 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     while ((double)nbin * 6000.0 < entries && nbin < (u32)pl.NB) { nbin <<= 1; lg++; }
     int LB = bc - 1 - (int)lg;
     while (LB > 0 && (LB > 11 || vbits + (u32)LB + 1 > 32)) { nbin <<= 1; LB--; }
-    if (vbits + (u32)LB + 1 > 32 || (size_t)nbin * 4 > 64 * 1024) return BP_OK;
+    if (vbits + (u32)LB + 1 > 32 || (size_t)nbin * 4 > 64 * 1024) FBX(5);
     // expected load of the fullest bin: every full window spreads n(1 - 2^-c) digits uniformly; the top window (tb bits) only reaches
     // the lowest 2^(tb-1) buckets
     const int tb = bits - bc * (pl.W - 1);
     double mu = (double)n * (pl.W - 1) / nbin;
     if (tb > 0) { const double reach = std::max(1.0, std::ldexp(1.0, tb - 1) / (double)((u32)1 << LB)); mu += (double)n / std::min<double>(reach, nbin); }
     const size_t cap = (size_t)(mu + 8.0 * std::sqrt(mu) + 64.0);
-    if ((((size_t)1 << LB) + 4 + cap) * 4 > 64 * 1024 || (size_t)nbin * cap >= ((size_t)1 << 31)) return BP_OK;
+    if ((((size_t)1 << LB) + 4 + cap) * 4 > 64 * 1024 || (size_t)nbin * cap >= ((size_t)1 << 31)) FBX(6);
     BinPlan bp; memset(&bp, 0, sizeof bp);
     bp.LB = (u32)LB; bp.NBIN = nbin; bp.cap = (u32)cap; bp.wb = 1; bp.tpt = (u32)std::min<size_t>(16, std::max<size_t>(1, n / (256 * 512)));
     SlotPlan sp; memset(&sp, 0, sizeof sp);
@@ -1089,7 +1091,7 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     if (tot[NL + 1] != 0) {   // a bin region overflowed (skewed scalars): the ordinary MSM handles those
         HIPCHK(hipMemsetAsync(d_over, 0, 4, st));
         total.stop();
-        return BP_OK;
+        FBX(7);
     }
     result = G::inf();
     done = true;
@@ -1129,6 +1131,7 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     return reduce_after ? shard_point_reduce<C>(ctx, result) : BP_OK;
 }
 
+#undef FBX
 // MSM over the resident generator tables (no base upload): bases = G[off..off+n) (if use_G) || H[off..off+n) (if use_H) || extras
 struct MsmLatencyScope { bp_ctx* c; bool prev; MsmLatencyScope(bp_ctx* c_) : c(c_), prev(c_->msm_latency_first) { c->msm_latency_first = true; } ~MsmLatencyScope() { c->msm_latency_first = prev; } };
 template <class C> static int msm_gens_entry(bp_ctx* c, int use_G, int use_H, size_t off, size_t n, const uint64_t* extra_xy, size_t n_extra,

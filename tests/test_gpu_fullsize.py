@@ -164,20 +164,22 @@ def test_cfg5_prove_verify_2pow22(curve):
         e.close()
 
 
-def test_cfg5_2pow22_partitioned_across_two_ranks_equals_the_one_rank_proof():
+def test_cfg5_2pow22_partitioned_across_four_ranks_equals_the_one_rank_proof():
     """BASELINE cfg5 AS A WHOLE on one GPU: the 2^22-constraint proof through north_star's partition — Pippenger windows of the
-    commitment MSMs and the index-cyclic inner-product argument (2^21 elements per rank, gather at the frozen-tail length) — by two
-    ranks (threads, one Engine each, sharing ONE resident set of generator tables and first-round fold tables), exchanging partial
-    points and the tail vectors through an in-process all-gather.  Both ranks must emit exactly the bytes of the one-rank proof,
-    and the partitioned verifier (window-sharded mega-check) must accept it.  (the partition had run at 2^16, the
-    size on one rank — never both.)"""
+    commitment MSMs and the index-cyclic inner-product argument (2^20 elements per rank, gather at the frozen-tail length) — by FOUR
+    ranks (threads, one Engine each, sharing ONE resident set of generator tables, fold tables and fixed-base rows), exchanging partial
+    points and the tail vectors through an in-process all-gather.  Every rank must emit exactly the bytes of the one-rank proof,
+    the partitioned verifier (window-sharded mega-check) must accept it, and the ranks must have kept the single-GPU MSM algorithm:
+    fixed-base MSMs over their blocks of the commitments' terms and over the strided rows of the first round (four ranks: 2^21 + 1
+    terms per rank — the fixed-base schedule's entry words hold up to 2^22 terms).  (the partition had run at 2^16, the
+    size on one rank — never both; and the sharded prover stepped back to the ordinary schedule.)"""
     import threading
 
     import ark_bulletproofs_amd as A
     from ark_bulletproofs_amd import engine as E
     from ark_bulletproofs_amd import parallel as P
 
-    N, world, cv = 1 << 22, 2, 0
+    N, world, cv = 1 << 22, 4, 0
     seed = bytes([9]) * 32
     single = A.Engine(curve=cv)
     try:
