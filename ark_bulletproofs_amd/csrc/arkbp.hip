@@ -998,9 +998,7 @@ template <class C> static int fb_tables_build(bp_ctx* ctx, size_t cap) {
 // (no tables, a run beyond them, skewed scalars overflowing a bin region, window-sharded ctx): the caller then runs the
 // ordinary MSM over the same bases.
 template <class C>
-static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSegs& ssegs, size_t n, int scalars_mont, J4& result, bool& done,
-                         int shard_mode = -1 /* on a sharded ctx: 2 = the runs are THIS RANK'S share of the terms: all windows here, then the point-reduce
-                                                 (the single-GPU schedule at 1/world of the terms); anything else: step aside */) {
+static int msm_fixed_run_one(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSegs& ssegs, size_t n, int scalars_mont, J4& result, bool& done, int shard_mode) {
     typedef host::Grp<C> G;
     done = false;
     static const bool fbtrace = getenv("ARKBP_FB_TRACE") != nullptr;
@@ -1095,7 +1093,7 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     }
     result = G::inf();
     done = true;
-    if (tot[0] == 0) { total.stop(); return reduce_after ? shard_point_reduce<C>(ctx, result) : BP_OK; }
+    if (tot[0] == 0) { total.stop(); return BP_OK; }
     const u32 maxcnt = tot[NL];
     int K = 1;
     { u64 capl = (u64)1 << chl; while (capl < maxcnt) { capl <<= chl; K++; } }
@@ -1126,12 +1124,55 @@ static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSe
     const u64* T = (const u64*)ctx->h_T;
     J4 pnt; memcpy(pnt.X.v, T, 32); memcpy(pnt.Y.v, T + 4, 32); memcpy(pnt.Z.v, T + 8, 32);
     if (!pnt.Z.is_zero()) result = pnt;   // no Horner tail: the rows already carry the powers of two
+    return BP_OK;
+}
+#undef FBX
+// The entry word of the fixed-base sort packs (window, term, fine bucket, sign) into 32 bits: one call holds up to 2^22 terms.  Longer
+// MSMs — the commitments of a 2^22-constraint proof have 2^23 + 1 terms — go through in pieces of the logical term range (runs and
+// scalar segments cut alike), the partial points added on the host: the schedule's 13 mixed additions per term instead of the
+// ordinary 17-18 at every size.  On a sharded ctx (shard_mode 2: the runs are THIS RANK'S share of the terms — all windows here, the
+// single-GPU schedule at 1/world of the terms) ONE point-reduce follows, whatever the number of pieces; any other mode steps aside.
+static constexpr size_t FB_MAX_TERMS = (size_t)1 << 22;
+template <class C>
+static int msm_fixed_run(bp_ctx* ctx, const FbRun* runs, int nruns, const ScalSegs& ssegs, size_t n, int scalars_mont, J4& result, bool& done, int shard_mode = -1) {
+    typedef host::Grp<C> G;
+    done = false;
+    const bool reduce_after = ctx->shard_world > 1 && shard_mode == 2;
+    if (n <= FB_MAX_TERMS) {
+        BPCHK(msm_fixed_run_one<C>(ctx, runs, nruns, ssegs, n, scalars_mont, result, done, shard_mode));
+    } else {
+        if (ctx->shard_world > 1 && !reduce_after) return BP_OK;
+        const size_t pieces = (n + FB_MAX_TERMS - 1) / FB_MAX_TERMS, per = (n + pieces - 1) / pieces;
+        J4 acc = G::inf();
+        bool all = true;
+        for (size_t t0 = 0; t0 < n && all; t0 += per) {
+            const size_t t1 = std::min(n, t0 + per);
+            FbRun rs[MSM_MAXSEG]; int nr = 0;
+            ScalSegs ss; memset(&ss, 0, sizeof ss);
+            size_t at = 0;
+            for (int k = 0; k < nruns; k++) {          // the runs' share of [t0, t1)
+                const size_t lo = std::max(at, t0), hi = std::min(at + runs[k].count, t1);
+                if (lo < hi) { rs[nr] = runs[k]; rs[nr].first = runs[k].first + (lo - at) * runs[k].stride; rs[nr].count = hi - lo; nr++; }
+                at += runs[k].count;
+            }
+            u32 sat = 0;
+            for (int k = 0; k < ssegs.nseg; k++) {      // the scalar segments' share
+                const size_t lo = std::max<size_t>(ssegs.start[k], t0), hi = std::min<size_t>(ssegs.start[k + 1], t1);
+                if (lo < hi) { ss.ptr[ss.nseg] = ssegs.ptr[k] + (lo - ssegs.start[k]) * 8; ss.start[ss.nseg] = sat; sat += (u32)(hi - lo); ss.nseg++; }
+            }
+            ss.start[ss.nseg] = sat;
+            J4 part; bool ok = false;
+            BPCHK(msm_fixed_run_one<C>(ctx, rs, nr, ss, t1 - t0, scalars_mont, part, ok, shard_mode));
+            if (!ok) all = false; else acc = G::add(acc, part);
+        }
+        if (all) { result = acc; done = true; }
+    }
+    if (!done) return BP_OK;
     ctx->fb_runs++;
-    if (reduce_after) ctx->fb_runs_sharded++;
-    return reduce_after ? shard_point_reduce<C>(ctx, result) : BP_OK;
+    if (reduce_after) { ctx->fb_runs_sharded++; return shard_point_reduce<C>(ctx, result); }
+    return BP_OK;
 }
 
-#undef FBX
 // MSM over the resident generator tables (no base upload): bases = G[off..off+n) (if use_G) || H[off..off+n) (if use_H) || extras
 struct MsmLatencyScope { bp_ctx* c; bool prev; MsmLatencyScope(bp_ctx* c_) : c(c_), prev(c_->msm_latency_first) { c->msm_latency_first = true; } ~MsmLatencyScope() { c->msm_latency_first = prev; } };
 template <class C> static int msm_gens_entry(bp_ctx* c, int use_G, int use_H, size_t off, size_t n, const uint64_t* extra_xy, size_t n_extra,
