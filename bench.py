@@ -47,12 +47,24 @@ VALU_CYCLES_PER_PRODUCT = VALU_MAD64_PER_PRODUCT * 4 + VALU_OTHER_PER_PRODUCT * 
 VALU_PEAK_GMODMUL = 256 * 4 * 2.4e9 / VALU_CYCLES_PER_PRODUCT * 64 / 1e9        # 185.5 G modmul/s at the maximum clock
 VALU_MEASURED_GMODMUL = 169.0      # tools/ubench.hip on this GPU (profiles/r01_ubench_radix29.txt): the clock the chip holds under this load
 VALU_INSTR_PER_PRODUCT = VALU_MAD64_PER_PRODUCT + VALU_OTHER_PER_PRODUCT
+# The SCALAR fields of both curves are pseudo-Mersenne since round 4 (csrc/fp29.cuh fe_pm_product): a product there is 91 v_mad_u64_u32 +
+# ~150 full-rate instructions (hipcc -S of one-product kernels: 378 VALU instructions with 91 multiply-adds against 399 / 160 for the
+# Montgomery form of the base field, ~140 of either being the load / store / canonicalisation around the product).
+VALU_PM_MAD64_PER_PRODUCT, VALU_PM_OTHER_PER_PRODUCT = 91, 150
+VALU_PM_CYCLES_PER_PRODUCT = VALU_PM_MAD64_PER_PRODUCT * 4 + VALU_PM_OTHER_PER_PRODUCT * 2
+VALU_PM_PEAK_GMODMUL = 256 * 4 * 2.4e9 / VALU_PM_CYCLES_PER_PRODUCT * 64 / 1e9    # 238 G modmul/s
 MADD_PRODUCTS, JADD_PRODUCTS, DBL_PRODUCTS = 11, 16, 7        # modular products of a mixed addition / Jacobian addition / doubling (csrc/ec.cuh)
 
 
-def valu_entry(products, seconds, note):
-    """the integer-VALU view of a kernel (group): modular products it needs / its time, against the guide-derived ceiling"""
+def valu_entry(products, seconds, note, scalar_field=False):
+    """the integer-VALU view of a kernel (group): modular products it needs / its time, against the guide-derived ceiling
+    (scalar_field: the kernel multiplies in Fr — pseudo-Mersenne products, cheaper per product, higher ceiling)"""
     rate = products / seconds / 1e9
+    if scalar_field:
+        return {"unit": "G modmul/s", "achieved": rate, "peak": VALU_PM_PEAK_GMODMUL, "frac": rate / VALU_PM_PEAK_GMODMUL, "products": products,
+                "valu_instructions": products * (VALU_PM_MAD64_PER_PRODUCT + VALU_PM_OTHER_PER_PRODUCT),
+                "peak_derivation": "256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / (91 v_mad_u64_u32 x 4 cyc + 150 full-rate x 2 cyc): the pseudo-Mersenne product of the scalar "
+                                   "field (csrc/fp29.cuh fe_pm_product); the 4 cycles per v_mad_u64_u32 are MEASURED (tools/ubench.hip), the rest is the guide's", "note": note}
     return {"unit": "G modmul/s", "achieved": rate, "peak": VALU_PEAK_GMODMUL, "frac": rate / VALU_PEAK_GMODMUL,
             "measured_rate": VALU_MEASURED_GMODMUL, "frac_of_measured_rate": rate / VALU_MEASURED_GMODMUL,
             "products": products, "valu_instructions": products * VALU_INSTR_PER_PRODUCT,
@@ -935,8 +947,8 @@ def run_verify(args, rank, world, local):
                            "traffic": traffic,
                            "traffic_note": "below the algorithmic bytes: the 2N scalars of a proof are never materialised (fused into the alpha-weighted accumulation)",
                            "avg_kernel_ms": vs_ms / vs_n, "algorithmic_bytes_per_verify": per_proof_bytes,
-                           "valu": valu_entry(products, avg_s, "k_vfy_batch is integer-VALU-bound: ~%.1f modular products per (proof, element) against the ceiling derived "
-                                              "from the guide's issue rates; SQ counters of this kernel: profiles/r0x_sq_vfy_batch_*.txt" % prod_pe),
+                           "valu": valu_entry(products, avg_s, "k_vfy_batch is integer-VALU-bound: ~%.1f modular products per (proof, element) in the scalar field "
+                                              "(pseudo-Mersenne since round 4) against the ceiling derived from the issue rates" % prod_pe, scalar_field=True),
                            "kernels": [kernel_entry("k_vfy_batch", vs_ms / vs_n, 1, 160.0 * N * nproofs_per_launch, traffic, products),
                                        kernel_entry("k_vfy_tables (per-proof split tables)", tb_ms / max(tb_n, 1), 1, None, None, None)] + fe_rows}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
