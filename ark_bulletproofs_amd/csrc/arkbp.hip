@@ -24,6 +24,7 @@
 #include "host_proto.hpp"
 #include "r1cs.cuh"
 #include "pedersen.cuh"
+#include "small.cuh"
 #include "vfe.hpp"
 #include "vfe_sched.hpp"
 static_assert(arkbp::vfe::PB_WORDS == arkbp::VFY_PB_WORDS, "parameter block layout shared by vfe.hip and r1cs.cuh");
@@ -213,6 +214,7 @@ struct IpaState {
     // tables for one more round, and the second fold produces Ghat'' / Hhat'' straight from the tables
     bool deferred = false;
     F4 def_tG, def_tH;
+    bool direct = false;        // frozen from round 1 over the ctx's generator tables, L and R as sums over the direct window tables (small.cuh)
     F4 geo_k0;                  // index-cyclic slices: the geometric H factor of local element j is K * rho^(rank + j*world) = (K * geo_k0) * (rho^world)^j
     bool have_k0 = false;
 };
@@ -301,6 +303,13 @@ struct bp_ctx {
     DevBuf ftab_G, ftab_H;
     size_t ftab_n = 0;       // bases covered: G[0..ftab_n), H[0..ftab_n)
     int ftab_w = 0, ftab_nwin = 0;
+    // direct window tables of the first generators (small.cuh): bases [B, B_blinding | G[0..dt_cap) | H[0..dt_cap)], built on the first
+    // small statement this ctx proves
+    DevBuf dt_tab, dt_part;
+    size_t dt_cap = 0;
+    size_t tune_direct_max = 4096;   // BP_TUNE_DIRECT_MAX: padded sizes up to this one prove over the direct tables (0 = never)
+    u32* h_dt = nullptr;             // pinned: the results of one launch
+    uint64_t dt_runs = 0;            // MSMs answered from the direct tables
     IpaState ipa_step;         // bp_ipa_begin .. bp_ipa_finish
     bool ipa_step_active = false;
     u32* h_totals = nullptr;  // pinned
@@ -1533,6 +1542,67 @@ template <class C> static int launch_tab_fold2(bp_ctx* ctx, const IpaState& s, u
     return BP_OK;
 }
 
+// ---- direct window tables of the first generators (small.cuh): the small-statement path --------------------------------------------
+static inline u32 dt_base_pc(int which /* 0 = B, 1 = B_blinding */) { return (u32)which; }
+static inline u32 dt_base_G(const bp_ctx* ctx, size_t i) { (void)ctx; return (u32)(2 + i); }
+static inline u32 dt_base_H(const bp_ctx* ctx, size_t i) { return (u32)(2 + ctx->dt_cap + i); }
+// true when statements of padded size N go over the direct tables on this ctx (building them on first use)
+template <class C> static int dt_ensure(bp_ctx* ctx, size_t N, bool& ready) {
+    ready = false;
+    if (!ctx->tune_direct_max || N == 0 || N > ctx->tune_direct_max || ctx->shard_world > 1 || ctx->gens_cap < N) return BP_OK;
+    if (ctx->dt_cap >= N) { ready = true; return BP_OK; }
+    if (!ctx->dt_tab.owned && ctx->dt_tab.p) { ctx->dt_tab.p = nullptr; ctx->dt_tab.cap = 0; ctx->dt_tab.owned = true; }   // (a shared table that is too short: build our own)
+    hipStream_t st = ctx->stream;
+    const size_t cap = std::min(ctx->gens_cap, ctx->tune_direct_max), nb = 2 + 2 * cap;
+    ctx->dt_cap = 0;
+    BPCHK(ctx->dt_tab.ensure_exact(nb * DT_BASE_BYTES));
+    DevBuf ws;
+    BPCHK(ws.ensure(nb * DT_WINDOWS * 96));
+    auto part = [&](const u32* bases, size_t first, size_t count) -> int {
+        hipLaunchKernelGGL(k_dt_window_bases<C>, dim3((u32)((count + 63) / 64)), dim3(64), 0, st, bases, (u32)count, ws.as<u32>() + first * DT_WINDOWS * 24);
+        return BP_OK;
+    };
+    BPCHK(part(ctx->d_pc.as<u32>(), 0, 2));
+    BPCHK(part(ctx->d_G.as<u32>(), 2, cap));
+    BPCHK(part(ctx->d_H.as<u32>(), 2 + cap, cap));
+    const size_t entries = nb * DT_PER_BASE;
+    hipLaunchKernelGGL(k_dt_entries<C>, dim3((u32)((entries + 255) / 256)), dim3(256), 0, st, ws.as<u32>(), (u32)nb, ctx->dt_tab.as<u32>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(ctx_stream_wait(ctx));
+    ws.release();
+    ctx->dt_cap = cap;
+    ready = true;
+    return BP_OK;
+}
+// nout MSMs over the direct tables in one launch (+ one finishing launch when more than one workgroup per MSM is worth it)
+template <class C> static int msm_direct(bp_ctx* ctx, const DtJobs& jobs, int nout, J4* results) {
+    typedef host::Grp<C> G;
+    hipStream_t st = ctx->stream;
+    u32 maxterms = 0;
+    for (int o = 0; o < nout; o++) maxterms = std::max(maxterms, jobs.job[o].terms);
+    // ~4 (term, window) pairs per lane: a mixed addition is ~6 us on a lane, a level of the workgroup's tree ~3 us
+    const u32 nblk = (u32)std::min<size_t>(512, std::max<size_t>(1, ((size_t)maxterms * DT_WINDOWS + 1023) / 1024));
+    BPCHK(ctx->dt_part.ensure((size_t)DT_MAXOUT * (nblk + 1) * 96));
+    if (!ctx->h_dt) HIPCHK(hipHostMalloc((void**)&ctx->h_dt, DT_MAXOUT * 96));
+    u32* part = ctx->dt_part.as<u32>();
+    u32* res = part + (size_t)DT_MAXOUT * nblk * 24;
+    {
+        ScopedK tk(ctx, BP_K_MSM_ACCUM);
+        hipLaunchKernelGGL(k_dt_accum<C>, dim3(nblk, (u32)nout), dim3(256), 0, st, ctx->dt_tab.as<u32>(), jobs, nblk == 1 ? res : part);
+        if (nblk > 1) hipLaunchKernelGGL(k_dt_finish<C>, dim3((u32)nout), dim3(256), 0, st, part, nblk, res);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_dt, res, (size_t)nout * 96, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx_stream_wait(ctx));
+    HIPCHK(hipGetLastError());
+    const u64* T = (const u64*)ctx->h_dt;
+    for (int o = 0; o < nout; o++) {
+        J4 pnt; memcpy(pnt.X.v, T + 12 * o, 32); memcpy(pnt.Y.v, T + 12 * o + 4, 32); memcpy(pnt.Z.v, T + 12 * o + 8, 32);
+        results[o] = pnt.Z.is_zero() ? G::inf() : pnt;
+    }
+    ctx->dt_runs += (uint64_t)nout;
+    return BP_OK;
+}
+
 // State of one InnerProductProof::create in flight (the loop body of src/inner_product_proof.rs:70-237 cut at the Fiat-Shamir
 // step): ipa_round_lr computes L, R of the current round, ipa_round_fold consumes the challenge.  ipa_create_dev drives it with a
 // callback; bp_ipa_begin / bp_ipa_round_LR / bp_ipa_round_fold / bp_ipa_finish expose the same steps for hosts that keep the
@@ -1572,7 +1642,26 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
         {
             ScopedK tk(ctx, BP_K_IPA_SCALARS);
             hipLaunchKernelGGL(k_ipa_frozen_scalars<C>, dim3(gf), dim3(256), 0, st, s.d_a, s.d_b, s.d_cG, s.d_cH, (u32)n, (u32)n0, sL, sR, ctx->ipa_part.as<u32>());
-            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gf, sL + 2 * n0 * 8, sR + 2 * n0 * 8, words_of<S>(s.qw), 0);
+            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gf, sL + 2 * n0 * 8, sR + 2 * n0 * 8, words_of<S>(s.qw), s.direct ? 1 : 0);
+        }
+        if (s.direct) {
+            // L and R as sums over the direct window tables, one launch for both: [G[0..n0) | H[0..n0) | B] with c * Q = (c * qw) * B
+            DtJobs jobs; memset(&jobs, 0, sizeof jobs);
+            for (int o = 0; o < 2; o++) {
+                const u32* sc = o ? sR : sL;
+                DtJob& jb = jobs.job[o];
+                jb.nseg = 3; jb.terms = (u32)(2 * n0 + 1);
+                jb.seg[0] = DtSeg{sc, dt_base_G(ctx, 0), (u32)n0, 0};
+                jb.seg[1] = DtSeg{sc + n0 * 8, dt_base_H(ctx, 0), (u32)n0, 0};
+                jb.seg[2] = DtSeg{sc + (2 * n0 + 1) * 8, dt_base_pc(0), 1, 0};
+            }
+            J4 LR[2];
+            BPCHK(msm_direct<C>(ctx, jobs, 2, LR));
+            A4 La = G::to_aff(LR[0]), Ra = G::to_aff(LR[1]);
+            memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
+            memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
+            s.lr_done = true;
+            return BP_OK;
         }
         BaseSegs sg; memset(&sg, 0, sizeof sg);
         sg.nseg = 3; sg.start[0] = 0; sg.start[1] = (u32)n0; sg.start[2] = (u32)(2 * n0); sg.start[3] = (u32)(2 * n0 + 1);
@@ -1828,13 +1917,25 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
                           const u32* d_rho_pow = nullptr /* device table of rho^(2^k), resident words */,
                           bool gens_are_tables = false /* d_G, d_H stand for the ctx's generator tables G[0..n), H[0..n) */,
                           bool gens_in_place = false /* ... and were NOT copied: round 1 reads ctx->d_G / d_H, d_G / d_H receive its output */,
-                          const F4* q_scalar = nullptr /* Q = q_scalar * B (PedersenGens::B) */) {
+                          const F4* q_scalar = nullptr /* Q = q_scalar * B (PedersenGens::B) */,
+                          bool direct = false /* (with gens_are_tables and q_scalar, n within the ctx's direct window tables) never fold G and H:
+                                                 the coefficients start as the factor vectors, every round's L and R are sums over the tables */) {
     IpaState s;
     BPCHK(ipa_begin_dev<C>(ctx, s, d_Q, d_Gf, d_Hf, d_G, d_H, d_a, d_b, n, gf_halves, rho_pw, d_rho_pow, true));
     if (gens_are_tables) { s.gens_first = 0; s.gens_stride = 1; }
     if (gens_in_place) { s.d_G_in = ctx->d_G.as<u32>(); s.d_H_in = ctx->d_H.as<u32>(); }
     if (n == 1) s.d_G_in = s.d_H_in = nullptr;
     if (q_scalar) { s.have_qw = true; s.qw = *q_scalar; }
+    if (direct && gens_are_tables && q_scalar && n >= 2 && ctx->dt_cap >= n) {
+        BPCHK(ctx->ipa_cG.ensure(n * 32)); BPCHK(ctx->ipa_cH.ensure(n * 32));
+        BPCHK(ctx->ipa_sL.ensure((2 * n + 2) * 32)); BPCHK(ctx->ipa_sR.ensure((2 * n + 2) * 32));
+        BPCHK(ctx->ipa_part.ensure(((n + 255) / 256 + 1) * 64));
+        HIPCHK(hipMemcpyAsync(ctx->ipa_cG.p, d_Gf, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->ipa_cH.p, d_Hf, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        s.d_cG = ctx->ipa_cG.as<u32>(); s.d_cH = ctx->ipa_cH.as<u32>();
+        s.d_G_in = s.d_H_in = nullptr;
+        s.frozen = true; s.direct = true; s.n0 = n;
+    }
     while (s.n != 1) {
         uint64_t Lw[8], Rw[8], uw[4];
         BPCHK(ipa_round_lr<C>(ctx, s, Lw, Rw));
@@ -2559,6 +2660,8 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* vbufs[] = {&c->vfe_in, &c->vfe_msg, &c->vfe_chal, &c->vfe_ws, &c->vfe_small};
     for (auto b : vbufs) b->release();
     if (c->h_vfe) (void)hipHostFree(c->h_vfe);
+    c->dt_tab.release(); c->dt_part.release();
+    if (c->h_dt) (void)hipHostFree(c->h_dt);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);
     for (int i = 0; i < 2; i++) { if (c->h_vstage[i]) (void)hipHostFree(c->h_vstage[i]); if (c->vstage_ev[i]) (void)hipEventDestroy(c->vstage_ev[i]); if (c->vtail_ev[i]) (void)hipEventDestroy(c->vtail_ev[i]); if (c->dec_ev[i]) (void)hipEventDestroy(c->dec_ev[i]); }
@@ -2652,6 +2755,7 @@ int bp_ctx_set_tuning(bp_ctx* c, int knob, uint64_t value) {
         case BP_TUNE_WAIT_SLEEP: if (value > 1000) return BP_E_ARG; c->tune_wait_sleep = value == 1 ? 30u : (unsigned)value; return BP_OK;
         case BP_TUNE_MSM_CHUNK_CAP: if (value && (value < 8 || value > 64)) return BP_E_ARG; c->tune_msm_chunk_cap = (size_t)value; return BP_OK;
         case BP_TUNE_VFY_DEVICE: c->tune_vfy_device = value != 0; return BP_OK;
+        case BP_TUNE_DIRECT_MAX: if (value > ((uint64_t)1 << 16)) return BP_E_ARG; c->tune_direct_max = (size_t)value; return BP_OK;
     }
     return BP_E_ARG;
 }
@@ -3177,6 +3281,8 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src) {
     DevBuf* dt[] = {&dst->ftab_G, &dst->ftab_H, &dst->fb_G, &dst->fb_H, &dst->fb_pc};
     DevBuf* stb[] = {&src->ftab_G, &src->ftab_H, &src->fb_G, &src->fb_H, &src->fb_pc};
     for (int i = 0; i < 5; i++) { dt[i]->release(); dt[i]->p = stb[i]->p; dt[i]->cap = stb[i]->cap; dt[i]->owned = false; }
+    dst->dt_tab.release(); dst->dt_cap = 0;
+    if (src->dt_cap) { dst->dt_tab.p = src->dt_tab.p; dst->dt_tab.cap = src->dt_tab.cap; dst->dt_tab.owned = false; dst->dt_cap = src->dt_cap; }
     dst->fb_cap = src->fb_cap;
     dst->ftab_n = src->ftab_n; dst->ftab_w = src->ftab_w; dst->ftab_nwin = src->ftab_nwin;
     return BP_OK;
@@ -3298,6 +3404,12 @@ int bp_debug_verify_challenges(int curve, size_t count, const int* scenarios, co
     if (!count || count > 8 || !scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !publics || !npubs || !out || !nchal) return BP_E_ARG;
     return curve == 0 ? dbg_verify_challenges<Secq>(count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, use_x8, out, nchal)
                       : dbg_verify_challenges<Zorro>(count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, use_x8, out, nchal);
+}
+int bp_ctx_direct_stats(bp_ctx* c, uint64_t* direct_msms, size_t* bases_per_vector) {
+    if (!c) return BP_E_ARG;
+    if (direct_msms) *direct_msms = c->dt_runs;
+    if (bases_per_vector) *bases_per_vector = c->dt_cap;
+    return BP_OK;
 }
 int bp_ctx_msm_stats(bp_ctx* c, uint64_t* fixed_base_runs, uint64_t* fixed_base_runs_sharded) {
     if (!c) return BP_E_ARG;

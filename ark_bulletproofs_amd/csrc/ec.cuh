@@ -122,8 +122,9 @@ template <class C> ARKBP_HD Jac jac_madd(const Jac& p, const Aff& q) {
     Fe V = fe_mul<F>(p.X, HH);      // <= 1.2
     Jac o;
     o.X = fe_wred<F>(fe_sub<F, 4>(fe_sqr<F>(r), fe_add(HHH, fe_dbl(V))));
-    Fe Y3 = fe_mul<F>(r, fe_sub<F, 4>(V, o.X));
-    o.Y = fe_wred<F>(fe_sub<F, 2>(Y3, fe_mul<F>(p.Y, HHH)));
+    // Y3 = r (V - X3) - Y1 H^3 as ONE fused product pair: a single Montgomery reduction for both products (243 limb products instead
+    // of 324) and no weak reduction after (V < (5.1 * 5.2 + 4 * 1.3) / 32 + 1 < 2)
+    o.Y = fe_mul2<F>(r, fe_sub<F, 4>(V, o.X), fe_neg<F, 4>(p.Y), HHH);
     o.Z = fe_mul<F>(p.Z, H);
     return o;
 }
@@ -147,8 +148,9 @@ template <class C> ARKBP_HD Jac jac_madd_fast(const Jac& p, const Aff& q, bool& 
     Fe V = fe_mul<F>(p.X, HH);      // <= 1.2
     Jac o;
     o.X = fe_wred<F>(fe_sub<F, 4>(fe_sqr<F>(r), fe_add(HHH, fe_dbl(V))));
-    Fe Y3 = fe_mul<F>(r, fe_sub<F, 4>(V, o.X));
-    o.Y = fe_wred<F>(fe_sub<F, 2>(Y3, fe_mul<F>(p.Y, HHH)));
+    // Y3 = r (V - X3) - Y1 H^3 as ONE fused product pair: a single Montgomery reduction for both products (243 limb products instead
+    // of 324) and no weak reduction after (V < (5.1 * 5.2 + 4 * 1.3) / 32 + 1 < 2)
+    o.Y = fe_mul2<F>(r, fe_sub<F, 4>(V, o.X), fe_neg<F, 4>(p.Y), HHH);
     o.Z = fe_mul<F>(p.Z, H);
     return o;
 }
@@ -172,8 +174,7 @@ template <class C> ARKBP_HD Jac jac_add(const Jac& p, const Jac& q) {
     Fe V = fe_mul<F>(U1, HH);
     Jac o;
     o.X = fe_wred<F>(fe_sub<F, 4>(fe_sqr<F>(r), fe_add(HHH, fe_dbl(V))));
-    Fe Y3 = fe_mul<F>(r, fe_sub<F, 4>(V, o.X));
-    o.Y = fe_wred<F>(fe_sub<F, 2>(Y3, fe_mul<F>(S1, HHH)));
+    o.Y = fe_mul2<F>(r, fe_sub<F, 4>(V, o.X), fe_neg<F, 2>(S1), HHH);   // (one reduction for both products, see jac_madd)
     o.Z = fe_mul<F>(fe_mul<F>(p.Z, q.Z), H);
     return o;
 }

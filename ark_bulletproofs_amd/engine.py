@@ -976,3 +976,13 @@ def _msm_stats(self):
 
 
 Engine.msm_stats = _msm_stats
+
+
+def _direct_stats(self):
+    """(MSMs answered from the direct window tables of the small-statement path, generators per vector the tables cover)"""
+    a, b = C.c_uint64(0), C.c_size_t(0)
+    check(lib().bp_ctx_direct_stats(self.ctx, C.byref(a), C.byref(b)), "bp_ctx_direct_stats")
+    return a.value, b.value
+
+
+Engine.direct_stats = _direct_stats

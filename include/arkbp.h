@@ -427,6 +427,11 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
                                      the GPU full; fitted per MSM to whole waves per SIMD for the bp_msm* entry points).  Results never depend on it */
 #define BP_TUNE_VFY_DEVICE 11    /* 1 (default): batch verification of like-instances of one single-phase statement runs its per-proof front end on the
                                   * GPU (see "verifier front end on the device" below); 0: always the host replay (A/B, tests) */
+#define BP_TUNE_DIRECT_MAX 12    /* statements whose padded size is at most this (default 4096, at most 2^16; 0 = never) are proved over DIRECT WINDOW
+                                  * TABLES of the first generators (d * 16^w * base, 60 KiB per base, built by the first such proof of the ctx): every
+                                  * MSM of Prover::prove (src/r1cs/prover.rs:516-649) and of InnerProductProof::create
+                                  * (src/inner_product_proof.rs:86-213) becomes a sum of table entries, G and H are never folded.  This is the
+                                  * latency path for the reference's own benchmark range (benches/r1cs_secq256k1.rs:152-250, 2 .. 2046 multipliers) */
 int bp_ctx_set_tuning(bp_ctx* ctx, int knob, uint64_t value);
 
 /* The O(N) part of `Verifier::verification_scalars` (src/r1cs/verifier.rs:465-514, s from inner_product_proof.rs:279-311) for a
@@ -483,6 +488,9 @@ int bp_ctx_vfe_stats(bp_ctx* ctx, uint64_t* device_batches, uint64_t* host_fallb
 /* MSMs over the generator tables that took the fixed-base schedule (bp_gens_msm_tables) on this ctx, and how many of those ran on a
  * rank's share of the terms of a sharded proof (blocks of a commitment's terms, the strided slice of the first IPA round) */
 int bp_ctx_msm_stats(bp_ctx* ctx, uint64_t* fixed_base_runs, uint64_t* fixed_base_runs_sharded);
+/* The small-statement path (BP_TUNE_DIRECT_MAX): MSMs this ctx answered from its direct window tables, and the number of generators
+ * per vector those tables cover (0 = not built yet) */
+int bp_ctx_direct_stats(bp_ctx* ctx, uint64_t* direct_msms, size_t* bases_per_vector);
 /* A ctx WITHOUT a device for sanitizer runs of the host layer on machines with no GPU (tools/sanitize/): only bp_r1cs_batch_verify,
  * bp_r1cs_batch_verify_scenarios, bp_ctx_set_tuning and bp_ctx_destroy accept it.  They run the complete host side of batch
  * verification — framing, square roots (on the host here), thread pools, shared recordings, transcript replay (live and lockstep),

@@ -56,6 +56,7 @@ def test_prove_large_round_kernels_at_small_sizes(oracle, sc, prm, freeze):
     for cv in (0, 1):
         e = A.Engine(curve=cv)
         e.gens_derive(128)
+        e.set_tuning(12, 0)           # BP_TUNE_DIRECT_MAX: not the small-statement path (tests/test_gpu_small.py) — the schedules below
         e.set_tuning(0, 1)
         e.set_tuning(1, 1)
         e.set_tuning(2, freeze)
@@ -273,6 +274,7 @@ def test_prove_with_first_round_fold_tables(oracle, w):
     for cv in (0, 1):
         e = A.Engine(curve=cv)
         e.gens_derive(1024)
+        e.set_tuning(12, 0)           # BP_TUNE_DIRECT_MAX: not the small-statement path (tests/test_gpu_small.py) — the schedules below
         wb, nbytes = e.gens_fold_tables(256, window_bits=w)
         assert 2 <= wb <= 8 and nbytes > 0 and (w == 0 or wb == w)
         for batch_min in (65536, 1):
@@ -283,6 +285,7 @@ def test_prove_with_first_round_fold_tables(oracle, w):
                 assert got.proof == ref.proof, (cv, w, sc, prm)
         # the tables go along with bp_gens_share
         e2 = A.Engine(curve=cv)
+        e2.set_tuning(12, 0)
         e2.share_gens_from(e)
         ref = oracle.r1cs_prove(cv, 3, [300, 0], SEED, 1024, m_cap=8)
         assert e2.prove_scenario(3, [300, 0], SEED, m_cap=8).proof == ref.proof
@@ -302,6 +305,7 @@ def test_prove_with_fixed_base_msm_tables(oracle, fold_tables):
     for cv in (0, 1):
         e = A.Engine(curve=cv)
         e.gens_derive(4096)
+        e.set_tuning(12, 0)           # BP_TUNE_DIRECT_MAX: not the small-statement path (tests/test_gpu_small.py) — the schedules below
         assert e.gens_msm_tables(4096) > 0
         e.set_tuning(5, 4096)      # BP_TUNE_MSM_FIXED_MIN: take the fixed-base schedule at these sizes
         if fold_tables:
@@ -329,6 +333,7 @@ def test_prove_two_fold_rounds_from_the_tables(oracle, w):
         try:
             N = 4096
             e.gens_derive(N)
+            e.set_tuning(12, 0)           # BP_TUNE_DIRECT_MAX: not the small-statement path (tests/test_gpu_small.py) — the schedules below
             wb, nbytes = e.gens_fold_tables(N * 3 // 4, window_bits=w)
             assert nbytes > 0 and (w == 0 or wb == w)
             e.set_tuning(2, 16)        # BP_TUNE_IPA_FREEZE_LEN: the frozen tail starts at 16 so that small statements defer their first fold
@@ -365,6 +370,7 @@ def test_prove_with_quad_cooperative_fold_rounds(oracle):
         e = A.Engine(curve=cv)
         try:
             e.gens_derive(2048)
+            e.set_tuning(12, 0)           # BP_TUNE_DIRECT_MAX: not the small-statement path (tests/test_gpu_small.py) — the schedules below
             e.set_tuning(8, 1 << 12)     # BP_TUNE_FOLD_QUAD_MAX
             e.set_tuning(2, 8)           # BP_TUNE_IPA_FREEZE_LEN
             for batch_min in (65536, 1):
