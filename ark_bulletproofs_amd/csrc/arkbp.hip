@@ -238,6 +238,7 @@ struct bp_ctx {
     // generator tables (BulletproofGens party 0, PedersenGens), resident layout
     DevBuf d_G, d_H, d_pc;
     DevBuf pc_table;   // fixed-base window tables of B, B_blinding (pedersen.cuh), built on first use
+    DevBuf pc_dt;      // direct window tables of B, B_blinding (small.cuh k_dt_commit)
     size_t gens_cap = 0;
     A4 pc_B, pc_Bb;
     // R1CS prover / verifier vectors (resident scalar layout)
@@ -1574,14 +1575,14 @@ template <class C> static int dt_ensure(bp_ctx* ctx, size_t N, bool& ready) {
     ready = true;
     return BP_OK;
 }
-// nout MSMs over the direct tables in one launch (+ one finishing launch when more than one workgroup per MSM is worth it)
-template <class C> static int msm_direct(bp_ctx* ctx, const DtJobs& jobs, int nout, J4* results) {
-    typedef host::Grp<C> G;
+// nout MSMs over the direct tables in one launch (+ one finishing launch when more than one workgroup per MSM is worth it): the
+// launch half leaves the results on their way to pinned memory, the collect half reads them after the caller's stream wait
+template <class C> static int msm_direct_launch(bp_ctx* ctx, const DtJobs& jobs, int nout) {
     hipStream_t st = ctx->stream;
     u32 maxterms = 0;
     for (int o = 0; o < nout; o++) maxterms = std::max(maxterms, jobs.job[o].terms);
-    // ~4 (term, window) pairs per lane: a mixed addition is ~6 us on a lane, a level of the workgroup's tree ~3 us
-    const u32 nblk = (u32)std::min<size_t>(512, std::max<size_t>(1, ((size_t)maxterms * DT_WINDOWS + 1023) / 1024));
+    // ~8 (term, window) pairs per quad: a quad-cooperative mixed addition is ~3 us, the workgroup's tree ~6 levels of the same
+    const u32 nblk = (u32)std::min<size_t>(256, std::max<size_t>(1, ((size_t)maxterms * DT_WINDOWS + 511) / 512));
     BPCHK(ctx->dt_part.ensure((size_t)DT_MAXOUT * (nblk + 1) * 96));
     if (!ctx->h_dt) HIPCHK(hipHostMalloc((void**)&ctx->h_dt, DT_MAXOUT * 96));
     u32* part = ctx->dt_part.as<u32>();
@@ -1592,15 +1593,38 @@ template <class C> static int msm_direct(bp_ctx* ctx, const DtJobs& jobs, int no
         if (nblk > 1) hipLaunchKernelGGL(k_dt_finish<C>, dim3((u32)nout), dim3(256), 0, st, part, nblk, res);
     }
     HIPCHK(hipMemcpyAsync(ctx->h_dt, res, (size_t)nout * 96, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx_stream_wait(ctx));
-    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+template <class C> static void msm_direct_collect(bp_ctx* ctx, int nout, J4* results) {
+    typedef host::Grp<C> G;
     const u64* T = (const u64*)ctx->h_dt;
     for (int o = 0; o < nout; o++) {
         J4 pnt; memcpy(pnt.X.v, T + 12 * o, 32); memcpy(pnt.Y.v, T + 12 * o + 4, 32); memcpy(pnt.Z.v, T + 12 * o + 8, 32);
         results[o] = pnt.Z.is_zero() ? G::inf() : pnt;
     }
     ctx->dt_runs += (uint64_t)nout;
+}
+template <class C> static int msm_direct(bp_ctx* ctx, const DtJobs& jobs, int nout, J4* results) {
+    BPCHK(msm_direct_launch<C>(ctx, jobs, nout));
+    HIPCHK(ctx_stream_wait(ctx));
+    HIPCHK(hipGetLastError());
+    msm_direct_collect<C>(ctx, nout, results);
     return BP_OK;
+}
+// affine forms of several Jacobian points with ONE field inversion (Montgomery's trick; the identity stays (0, 0))
+template <class C> static void to_aff_batch(const J4* in, int count, A4* out) {
+    typedef host::Grp<C> G;
+    typedef host::Fld<typename C::Fq> F;
+    F4 pref[DT_MAXOUT];
+    F4 run = F::one();
+    for (int i = 0; i < count; i++) { pref[i] = run; if (!G::is_inf(in[i])) run = F::mul(run, in[i].Z); }
+    F4 inv = F::inv(run);
+    for (int i = count - 1; i >= 0; i--) {
+        if (G::is_inf(in[i])) { out[i] = G::aff_inf(); continue; }
+        const F4 zi = F::mul(inv, pref[i]), zi2 = F::sqr(zi);
+        inv = F::mul(inv, in[i].Z);
+        out[i] = A4{F::mul(in[i].X, zi2), F::mul(in[i].Y, F::mul(zi2, zi))};
+    }
 }
 
 // State of one InnerProductProof::create in flight (the loop body of src/inner_product_proof.rs:70-237 cut at the Fiat-Shamir
@@ -1650,14 +1674,18 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
             for (int o = 0; o < 2; o++) {
                 const u32* sc = o ? sR : sL;
                 DtJob& jb = jobs.job[o];
-                jb.nseg = 3; jb.terms = (u32)(2 * n0 + 1);
-                jb.seg[0] = DtSeg{sc, dt_base_G(ctx, 0), (u32)n0, 0};
-                jb.seg[1] = DtSeg{sc + n0 * 8, dt_base_H(ctx, 0), (u32)n0, 0};
-                jb.seg[2] = DtSeg{sc + (2 * n0 + 1) * 8, dt_base_pc(0), 1, 0};
+                // every base belongs to exactly one of L, R (k_ipa_frozen_scalars): L takes G where the element sits in the upper half
+                // of its period of the current length and H in the lower half, R the other way round — only those are visited
+                jb.nseg = 3; jb.terms = (u32)(n0 + 1);
+                jb.seg[0] = DtSeg{sc, dt_base_G(ctx, 0), (u32)(n0 / 2), 0, (u32)n, o == 0 ? 1u : 0u};
+                jb.seg[1] = DtSeg{sc + n0 * 8, dt_base_H(ctx, 0), (u32)(n0 / 2), 0, (u32)n, o == 0 ? 0u : 1u};
+                jb.seg[2] = DtSeg{sc + (2 * n0 + 1) * 8, dt_base_pc(0), 1, 0, 0, 0};
             }
             J4 LR[2];
             BPCHK(msm_direct<C>(ctx, jobs, 2, LR));
-            A4 La = G::to_aff(LR[0]), Ra = G::to_aff(LR[1]);
+            A4 LRa[2];
+            to_aff_batch<C>(LR, 2, LRa);
+            const A4 &La = LRa[0], &Ra = LRa[1];
             memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
             memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
             s.lr_done = true;
@@ -2660,7 +2688,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* vbufs[] = {&c->vfe_in, &c->vfe_msg, &c->vfe_chal, &c->vfe_ws, &c->vfe_small};
     for (auto b : vbufs) b->release();
     if (c->h_vfe) (void)hipHostFree(c->h_vfe);
-    c->dt_tab.release(); c->dt_part.release();
+    c->dt_tab.release(); c->dt_part.release(); c->pc_dt.release();
     if (c->h_dt) (void)hipHostFree(c->h_dt);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);

@@ -456,7 +456,7 @@ template <class C> struct PedersenGens {
     // optional: all commitments of a statement in one call (the engine installs its GPU fixed-base kernel here)
     std::function<int(const F4* v, const F4* blind, size_t m, A4* out)> batch;
     int commit_many(const F4* v, const F4* blind, size_t m, A4* out) const {
-        if (batch && m > 16) return batch(v, blind, m, out);   // (a handful of commitments: the host's fixed-base tables beat a launch + a wait)
+        if (batch && m > 3) return batch(v, blind, m, out);   // (up to three commitments: the host's fixed-base tables, ~25 us each, beat a launch + a wait)
         for (size_t i = 0; i < m; i++) out[i] = commit(v[i], blind[i]);
         return BP_OK;
     }

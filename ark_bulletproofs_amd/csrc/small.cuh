@@ -15,6 +15,7 @@
 // elements, so L, R (and everything else) are bit-identical to the folding schedule's.
 #pragma once
 #include "ipa.cuh"
+#include "ecq.cuh"
 
 namespace arkbp {
 
@@ -60,10 +61,15 @@ k_dt_entries(const u32* __restrict__ ws, u32 nb, u32* __restrict__ tab) {
 // ---- sums over the tables --------------------------------------------------------------------------------------------------------
 // One MSM = up to DT_MAXSEG runs of (scalars, consecutive bases) + one immediate term whose scalar comes with the launch (a
 // commitment's blinding factor: no copy).  Scalars: 8 words each, canonical integers or the resident form of C::Fr.
-static constexpr int DT_MAXSEG = 3, DT_MAXOUT = 4;
+// A run may take every other block of `fold_n` elements of its vectors: term j stands for element
+//   t = (j / fold_n) * 2 * fold_n + (j % fold_n) + (fold_hi ? fold_n : 0)
+// — a frozen round of the inner-product argument pairs G with one half of every period of the current length and H with the other
+// (ipa.cuh k_ipa_frozen_scalars); the elements of the other half have zero scalars and are not even visited.
+static constexpr int DT_MAXSEG = 3, DT_MAXOUT = 6;
 struct DtSeg {
     const u32* sc;
-    u32 base0, count, resident;
+    u32 base0, count, resident;   // resident: 0 = canonical integers, 1 = the resident form of C::Fr, 2 = ark Montgomery words
+    u32 fold_n, fold_hi;
 };
 struct DtJob {
     DtSeg seg[DT_MAXSEG];
@@ -100,17 +106,37 @@ template <class C> __device__ __forceinline__ Jac load_jac_ark(const u32* __rest
     return r;
 }
 
-// grid (nblk, nout).  Pair p = term * 64 + window: the 64 lanes of a wave share a term's scalar (one broadcast load) and read 64
-// entries of that base's 60 KiB.  out: [nout][nblk] points (ark words); with nblk == 1 these are the results.
+// Everything here is latency: a lone lane needs ~8 us per point addition.  So FOUR lanes share every addition (ecq.cuh: one modular
+// product per lane and dependency level, ~2.5-3 us) — a quad walks its (term, window) pairs with quad-cooperative mixed additions,
+// the next table entry in flight meanwhile, and the 64 quads of a workgroup meet in a 6-level tree of quad-cooperative additions.
+// sh: 64 x 27 words.  Result valid in every lane of quad 0.
+template <class C> __device__ __forceinline__ Jac dt_quad_tree(const Jac& acc, u32* __restrict__ sh) {
+    const u32 q = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+    if (q == 0) lds_put_jac(sh, 64, quad, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (u32 half = 32; half >= 1; half >>= 1) {
+        // quad j < half: slot j += slot j + half (no quad of the level reads a slot another one writes)
+        if (quad < half) {
+            const Jac r = qjac_add<C>(lds_get_jac(sh, 64, quad), lds_get_jac(sh, 64, quad + half), q);
+            if (q == 0) lds_put_jac(sh, 64, quad, r);
+        }
+        __syncthreads();
+    }
+    return lds_get_jac(sh, 64, 0);
+}
+// grid (nblk, nout), 256 lanes = 64 quads.  Pair p = term * 64 + window: the 16 quads of a wave share a term's scalar (a broadcast
+// load) and read 16 entries of that base's 60 KiB.  out: [nout][nblk] points (ark words); with nblk == 1 these are the results.
 template <class C> __global__ void __launch_bounds__(256)
 k_dt_accum(const u32* __restrict__ tab, DtJobs jobs, u32* __restrict__ out) {
     typedef typename C::Fr Fr;
-    __shared__ u32 sh[256 * 27];
+    __shared__ u32 sh[64 * 27];
     const DtJob& jb = jobs.job[blockIdx.y];
     const u32 pairs = jb.terms * DT_WINDOWS;
-    Jac acc = jac_inf<C>();
-#pragma unroll 1
-    for (u32 p = blockIdx.x * 256u + threadIdx.x; p < pairs; p += gridDim.x * 256u) {
+    const u32 q = threadIdx.x & 3u, nquads = gridDim.x * 64u;
+    // the table entry of pair p (false: digit 0, or p past the end)
+    auto fetch = [&](u32 p, Aff& pt) -> bool {
+        if (p >= pairs) return false;
         u32 term = p / DT_WINDOWS;
         const u32 w = p % DT_WINDOWS;
         u32 k[8];
@@ -123,24 +149,80 @@ k_dt_accum(const u32* __restrict__ tab, DtJobs jobs, u32* __restrict__ out) {
             term -= jb.has_imm;
             u32 s = 0;
             while (s + 1 < jb.nseg && term >= jb.seg[s].count) { term -= jb.seg[s].count; s++; }
-            load_words8(k, jb.seg[s].sc + (size_t)term * 8);
-            if (jb.seg[s].resident) fe_store_canon<Fr>(k, fe_unpack(k));
-            base = jb.seg[s].base0 + term;
+            const DtSeg& sg = jb.seg[s];
+            if (sg.fold_n) term = (term / sg.fold_n) * 2u * sg.fold_n + (term % sg.fold_n) + (sg.fold_hi ? sg.fold_n : 0u);
+            load_words8(k, sg.sc + (size_t)term * 8);
+            if (sg.resident == 1) fe_store_canon<Fr>(k, fe_unpack(k));
+            else if (sg.resident == 2) fe_store_canon<Fr>(k, fe_load_ark<Fr>(k));
+            base = sg.base0 + term;
         }
         const u32 d = (k[w >> 3] >> (4u * (w & 7u))) & 15u;
-        if (d) acc = jac_madd<C>(acc, load_aff_dev(tab + (((size_t)base * DT_WINDOWS + w) * DT_ENT + (d - 1u)) * 16));
+        if (!d) return false;
+        pt = load_aff_dev(tab + (((size_t)base * DT_WINDOWS + w) * DT_ENT + (d - 1u)) * 16);
+        return true;
+    };
+    Jac acc = jac_inf<C>();
+    u32 p = blockIdx.x * 64u + (threadIdx.x >> 2);
+    Aff cur = {}, nxt = {};
+    bool have = fetch(p, cur);
+#pragma unroll 1
+    while (p < pairs) {
+        p += nquads;
+        const bool have_n = fetch(p, nxt);            // (in flight during the addition below)
+        if (have) acc = qjac_madd<C>(acc, cur, q);   // (quad-uniform: the four lanes fetched the same entry)
+        cur = nxt; have = have_n;
     }
-    acc = block_sum_jac_quad<C>(acc, sh);
+    acc = dt_quad_tree<C>(acc, sh);
     if (threadIdx.x == 0) store_jac_ark<C>(out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 24, acc);
 }
 // grid (nout): sum of the nblk partial points of output blockIdx.x -> res[blockIdx.x]
 template <class C> __global__ void __launch_bounds__(256)
 k_dt_finish(const u32* __restrict__ part, u32 nblk, u32* __restrict__ res) {
-    __shared__ u32 sh[256 * 27];
+    __shared__ u32 sh[64 * 27];
+    const u32 q = threadIdx.x & 3u;
     Jac acc = jac_inf<C>();
-    for (u32 j = threadIdx.x; j < nblk; j += 256) acc = jac_add<C>(acc, load_jac_ark<C>(part + ((size_t)blockIdx.x * nblk + j) * 24));
-    acc = block_sum_jac_quad<C>(acc, sh);
+#pragma unroll 1
+    for (u32 j = threadIdx.x >> 2; j < nblk; j += 64) acc = qjac_add<C>(acc, load_jac_ark<C>(part + ((size_t)blockIdx.x * nblk + j) * 24), q);
+    acc = dt_quad_tree<C>(acc, sh);
     if (threadIdx.x == 0) store_jac_ark<C>(res + (size_t)blockIdx.x * 24, acc);
+}
+
+// Pedersen commitments of a statement's inputs (PedersenGens::commit, src/generators.rs:39-44; one per Prover::commit,
+// src/r1cs/prover.rs:327-341) when there are few of them and the caller waits: ONE WAVE per commitment — its 16 quads walk the 128
+// (base, window) pairs of v * B + blind * B_blinding, 8 each, and meet in a 4-level tree of cross-lane moves; the Jacobian result goes
+// to the host, which normalises the whole batch with one inversion.  (k_pc_commit — one lane per commitment, 8-bit windows — is the
+// throughput form for the 2^20 + 2 commitments of a wide statement: ~0.6 ms however few there are.)
+// tab: direct window tables of [B, B_blinding]; v, blind: ark Montgomery words; out: m x 24 ark words (Z = 0: identity).
+template <class C> __global__ void __launch_bounds__(256)
+k_dt_commit(const u32* __restrict__ tab, const u32* __restrict__ v, const u32* __restrict__ blind, u32 m, u32* __restrict__ out) {
+    typedef typename C::Fr Fr;
+    const u32 lane = threadIdx.x & 63u, q = lane & 3u, quad = lane >> 2;
+    const u32 i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (i >= m) return;   // (wave-uniform)
+    u32 kv[8], kb[8];
+    load_words8(kv, v + (size_t)i * 8); fe_store_canon<Fr>(kv, fe_load_ark<Fr>(kv));
+    load_words8(kb, blind + (size_t)i * 8); fe_store_canon<Fr>(kb, fe_load_ark<Fr>(kb));
+    auto fetch = [&](u32 j, Aff& pt) -> bool {   // pair j of this quad: base j / 4, window quad + 16 * (j % 4)
+        if (j >= 8u) return false;
+        const u32 b = j >> 2, w = quad + 16u * (j & 3u);
+        const u32 word = b ? kb[w >> 3] : kv[w >> 3];
+        const u32 d = (word >> (4u * (w & 7u))) & 15u;
+        if (!d) return false;
+        pt = load_aff_dev(tab + (((size_t)b * DT_WINDOWS + w) * DT_ENT + (d - 1u)) * 16);
+        return true;
+    };
+    Jac acc = jac_inf<C>();
+    Aff cur = {}, nxt = {};
+    bool have = fetch(0, cur);
+#pragma unroll 1
+    for (u32 j = 0; j < 8u; j++) {
+        const bool have_n = fetch(j + 1u, nxt);
+        if (have) acc = qjac_madd<C>(acc, cur, q);
+        cur = nxt; have = have_n;
+    }
+#pragma unroll 1
+    for (int off = 32; off >= 4; off >>= 1) acc = qjac_add<C>(acc, jac_shfl_down(acc, off), q);   // (quad j += quad j + off / 4; lanes past the live range compute unused sums)
+    if (lane == 0) store_jac_ark<C>(out + (size_t)i * 24, acc);
 }
 
 }  // namespace arkbp
