@@ -1043,6 +1043,10 @@ def run_shuffle_sweep(args, rank, world, local):
                 row.update({"cpu_prove_ms": (ref.t_prove + ref.t_setup) * 1e3, "cpu_prove_inside_prove_ms": ref.t_prove * 1e3, "cpu_verify_ms": tim[0] * 1e3 if tim else None,
                             "proof_bytes_identical": True})
             rows.append(row)
+        direct_msms, direct_cap = eng.direct_stats()
+        for r in rows:
+            if r["curve"] == CURVES[curve]:
+                r["small_statement_path"] = bool(direct_cap)   # csrc/small.cuh: direct window tables, no generator folding (BP_TUNE_DIRECT_MAX)
         eng.close()
     big = [r for r in rows if r["k"] == max(ks) and r["curve"] == CURVES[args.curve]][0]
     return {"metric": "kshuffle_prove_ms (k = 1024; the whole sweep under \"rows\")", "value": big["gpu_prove_ms"], "unit": "ms", "n_gpus": world, "steps": reps, "warmup": args.warmup,
