@@ -215,6 +215,10 @@ struct IpaState {
     bool deferred = false;
     F4 def_tG, def_tH;
     bool direct = false;        // frozen from round 1 over the ctx's generator tables, L and R as sums over the direct window tables (small.cuh)
+    // direct: the fold a challenge asks for is carried out by the NEXT round's k_dt_round (or by k_ipa_fold_ab after the last round)
+    bool fold_pending = false;
+    F4 pend_u, pend_ui;
+    u32 *d_a_alt = nullptr, *d_b_alt = nullptr;   // second buffer pair: a fused fold reads one pair and writes the other
     F4 geo_k0;                  // index-cyclic slices: the geometric H factor of local element j is K * rho^(rank + j*world) = (K * geo_k0) * (rho^world)^j
     bool have_k0 = false;
 };
@@ -306,9 +310,9 @@ struct bp_ctx {
     int ftab_w = 0, ftab_nwin = 0;
     // direct window tables of the first generators (small.cuh): bases [B, B_blinding | G[0..dt_cap) | H[0..dt_cap)], built on the first
     // small statement this ctx proves
-    DevBuf dt_tab, dt_part;
+    DevBuf dt_tab, dt_part, dt_a2, dt_b2, dt_ticket;
     size_t dt_cap = 0;
-    size_t tune_direct_max = 4096;   // BP_TUNE_DIRECT_MAX: padded sizes up to this one prove over the direct tables (0 = never)
+    size_t tune_direct_max = 8192;   // BP_TUNE_DIRECT_MAX: padded sizes up to this one prove over the direct tables (0 = never)
     u32* h_dt = nullptr;             // pinned: the results of one launch
     uint64_t dt_runs = 0;            // MSMs answered from the direct tables
     IpaState ipa_step;         // bp_ipa_begin .. bp_ipa_finish
@@ -1581,8 +1585,11 @@ template <class C> static int msm_direct_launch(bp_ctx* ctx, const DtJobs& jobs,
     hipStream_t st = ctx->stream;
     u32 maxterms = 0;
     for (int o = 0; o < nout; o++) maxterms = std::max(maxterms, jobs.job[o].terms);
-    // ~8 (term, window) pairs per quad: a quad-cooperative mixed addition is ~3 us, the workgroup's tree ~6 levels of the same
-    const u32 nblk = (u32)std::min<size_t>(256, std::max<size_t>(1, ((size_t)maxterms * DT_WINDOWS + 511) / 512));
+    // A quad-cooperative mixed addition is ~4.5 us with a SIMD to itself, the workgroup's tree six levels of the same: one unit (four
+    // additions) per quad while that leaves at most one workgroup per CU, two units beyond (the waves then share their SIMDs)
+    const size_t units = (size_t)maxterms * DT_UNITS_PER_TERM;
+    u32 nblk = (u32)std::max<size_t>(1, (units + 63) / 64);
+    if ((size_t)nblk * nout > 256) nblk = (u32)std::min<size_t>(1024, (units + 127) / 128);
     BPCHK(ctx->dt_part.ensure((size_t)DT_MAXOUT * (nblk + 1) * 96));
     if (!ctx->h_dt) HIPCHK(hipHostMalloc((void**)&ctx->h_dt, DT_MAXOUT * 96));
     u32* part = ctx->dt_part.as<u32>();
@@ -1663,10 +1670,16 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
     if (s.frozen) {
         const size_t n0 = s.n0;
         const u32 gf = (u32)((n0 + 255) / 256);
-        {
+        if (s.direct) {
+            // one launch: the fold the previous challenge asked for (into the other buffer pair), the scalars, the inner products
+            ScopedK tk(ctx, BP_K_IPA_SCALARS);
+            hipLaunchKernelGGL(k_dt_round<C>, dim3(gf), dim3(256), 0, st, s.d_a, s.d_b, s.d_a_alt, s.d_b_alt, s.d_cG, s.d_cH, (u32)n, (u32)n0, s.fold_pending ? 1 : 0,
+                               words_of<S>(s.pend_u), words_of<S>(s.pend_ui), sL, sR, ctx->ipa_part.as<u32>(), ctx->dt_ticket.as<u32>(), words_of<S>(s.qw));
+            if (s.fold_pending) { std::swap(s.d_a, s.d_a_alt); std::swap(s.d_b, s.d_b_alt); s.fold_pending = false; }
+        } else {
             ScopedK tk(ctx, BP_K_IPA_SCALARS);
             hipLaunchKernelGGL(k_ipa_frozen_scalars<C>, dim3(gf), dim3(256), 0, st, s.d_a, s.d_b, s.d_cG, s.d_cH, (u32)n, (u32)n0, sL, sR, ctx->ipa_part.as<u32>());
-            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gf, sL + 2 * n0 * 8, sR + 2 * n0 * 8, words_of<S>(s.qw), s.direct ? 1 : 0);
+            hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gf, sL + 2 * n0 * 8, sR + 2 * n0 * 8, words_of<S>(s.qw), 0);
         }
         if (s.direct) {
             // L and R as sums over the direct window tables, one launch for both: [G[0..n0) | H[0..n0) | B] with c * Q = (c * qw) * B
@@ -1824,6 +1837,19 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
         s.d_G_in = s.d_H_in = nullptr;
         return BP_OK;
     };
+    if (s.direct) {
+        // the next round's k_dt_round folds (a, b and the coefficients); after the last round only a[0], b[0] are left to form
+        if (n == 1) {
+            ScopedK tk(ctx, BP_K_IPA_FOLD);
+            hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(1), dim3(256), 0, st, s.d_a, s.d_b, 1u, words_of<S>(u), words_of<S>(ui));
+            tk.stop();
+            HIPCHK(hipGetLastError());
+        } else {
+            s.fold_pending = true; s.pend_u = u; s.pend_ui = ui;
+        }
+        s.round++; s.n = n; s.lr_done = false;
+        return BP_OK;
+    }
     if (s.frozen) {
         ScopedK tk(ctx, BP_K_IPA_FOLD);
         hipLaunchKernelGGL(k_ipa_fold_ab<C>, dim3(gb), dim3(256), 0, st, s.d_a, s.d_b, (u32)n, words_of<S>(u), words_of<S>(ui));
@@ -1960,7 +1986,10 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
         BPCHK(ctx->ipa_part.ensure(((n + 255) / 256 + 1) * 64));
         HIPCHK(hipMemcpyAsync(ctx->ipa_cG.p, d_Gf, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->ipa_cH.p, d_Hf, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        BPCHK(ctx->dt_a2.ensure(n * 16)); BPCHK(ctx->dt_b2.ensure(n * 16));   // (the folded vectors: at most n / 2 elements)
+        BPCHK(ctx->dt_ticket.ensure_zeroed(64, ctx->stream));
         s.d_cG = ctx->ipa_cG.as<u32>(); s.d_cH = ctx->ipa_cH.as<u32>();
+        s.d_a_alt = ctx->dt_a2.as<u32>(); s.d_b_alt = ctx->dt_b2.as<u32>();
         s.d_G_in = s.d_H_in = nullptr;
         s.frozen = true; s.direct = true; s.n0 = n;
     }
@@ -2688,7 +2717,7 @@ void bp_ctx_destroy(bp_ctx* c) {
     DevBuf* vbufs[] = {&c->vfe_in, &c->vfe_msg, &c->vfe_chal, &c->vfe_ws, &c->vfe_small};
     for (auto b : vbufs) b->release();
     if (c->h_vfe) (void)hipHostFree(c->h_vfe);
-    c->dt_tab.release(); c->dt_part.release(); c->pc_dt.release();
+    c->dt_tab.release(); c->dt_part.release(); c->pc_dt.release(); c->dt_a2.release(); c->dt_b2.release(); c->dt_ticket.release();
     if (c->h_dt) (void)hipHostFree(c->h_dt);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_T) (void)hipHostFree(c->h_T);

@@ -427,7 +427,7 @@ int bp_ctx_reset_profiling(bp_ctx* ctx);
                                      the GPU full; fitted per MSM to whole waves per SIMD for the bp_msm* entry points).  Results never depend on it */
 #define BP_TUNE_VFY_DEVICE 11    /* 1 (default): batch verification of like-instances of one single-phase statement runs its per-proof front end on the
                                   * GPU (see "verifier front end on the device" below); 0: always the host replay (A/B, tests) */
-#define BP_TUNE_DIRECT_MAX 12    /* statements whose padded size is at most this (default 4096, at most 2^16; 0 = never) are proved over DIRECT WINDOW
+#define BP_TUNE_DIRECT_MAX 12    /* statements whose padded size is at most this (default 8192, at most 2^16; 0 = never) are proved over DIRECT WINDOW
                                   * TABLES of the first generators (d * 16^w * base, 60 KiB per base, built by the first such proof of the ctx): every
                                   * MSM of Prover::prove (src/r1cs/prover.rs:516-649) and of InnerProductProof::create
                                   * (src/inner_product_proof.rs:86-213) becomes a sum of table entries, G and H are never folded.  This is the

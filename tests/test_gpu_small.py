@@ -1,4 +1,4 @@
-"""The small-statement path of the prover (include/arkbp.h BP_TUNE_DIRECT_MAX, csrc/small.cuh): for padded sizes up to 4096 every MSM of
+"""The small-statement path of the prover (include/arkbp.h BP_TUNE_DIRECT_MAX, csrc/small.cuh): for padded sizes up to BP_TUNE_DIRECT_MAX (default 8192) every MSM of
 Prover::prove (src/r1cs/prover.rs:516-649) and every round of InnerProductProof::create (src/inner_product_proof.rs:86-213) is a sum
 over direct window tables of the first generators, and G / H are never folded.  The proofs must be byte-identical to the oracle's and
 to the folding schedule's — the reference's own benchmark range (benches/r1cs_secq256k1.rs:152-250: k-shuffles, k = 2 .. 1024)."""
