@@ -2973,6 +2973,25 @@ int bp_gens_msm_tables(bp_ctx* c, size_t count, size_t* bytes_out) {
     if (bytes_out) *bytes_out = 2 * (size_t)FB_ROWS * count * 64;
     return BP_OK;
 }
+int bp_gens_direct_tables(bp_ctx* c, size_t count, size_t* bytes_out) {
+    if (!c) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes_out) *bytes_out = 0;
+    if (count == 0) { if (c->dt_tab.owned) c->dt_tab.release(); else { c->dt_tab.p = nullptr; c->dt_tab.cap = 0; c->dt_tab.owned = true; } c->dt_cap = 0; return BP_OK; }
+    if (!c->gens_cap) { g_err = "direct tables: no generators installed"; return BP_E_GENS_LENGTH; }
+    if (c->shard_world > 1 || !c->tune_direct_max) { g_err = "direct tables: the small-statement path is off on this ctx (sharded, or BP_TUNE_DIRECT_MAX = 0)"; return BP_E_ARG; }
+    const size_t want = std::min(std::min(count, c->gens_cap), c->tune_direct_max);
+    // dt_ensure builds for min(generators, BP_TUNE_DIRECT_MAX): narrow the knob for the build so that `count` is what is built
+    const size_t keep = c->tune_direct_max;
+    c->tune_direct_max = want;
+    if (c->dt_cap != want) c->dt_cap = 0;
+    bool ready = false;
+    const int rc = c->curve == 0 ? dt_ensure<Secq>(c, want, ready) : dt_ensure<Zorro>(c, want, ready);
+    c->tune_direct_max = keep;
+    if (rc) return rc;
+    if (bytes_out) *bytes_out = (2 + 2 * c->dt_cap) * DT_BASE_BYTES;
+    return BP_OK;
+}
 int bp_gens_fold_tables(bp_ctx* c, size_t count, int window_bits, size_t budget_bytes, int* window_bits_out, size_t* bytes_out) {
     if (!c || window_bits < 0 || window_bits == 1 || window_bits > 8) return BP_E_ARG;
     HIPCHK(hipSetDevice(c->device));

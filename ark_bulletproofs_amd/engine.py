@@ -986,3 +986,13 @@ def _direct_stats(self):
 
 
 Engine.direct_stats = _direct_stats
+
+
+def _gens_direct_tables(self, count):
+    """bp_gens_direct_tables: build (count > 0) or free (0) the direct window tables of the small-statement path; returns their size in bytes"""
+    nbytes = C.c_size_t(0)
+    check(lib().bp_gens_direct_tables(self.ctx, C.c_size_t(count), C.byref(nbytes)), "bp_gens_direct_tables")
+    return nbytes.value
+
+
+Engine.gens_direct_tables = _gens_direct_tables

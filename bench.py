@@ -1024,16 +1024,21 @@ def run_shuffle_sweep(args, rank, world, local):
             for _ in range(max(1, args.warmup)):
                 pr = eng.prove_scenario(E.SC_SHUFFLE, [k], seed, m_cap=m_cap)
                 assert eng.verify_scenario(E.SC_SHUFFLE, [k], pr.proof, pr.commitments, pr.publics) == 0
-            t0 = time.perf_counter()
+            # one call at a time, as criterion does; the MEDIAN of the calls is the row's figure (a single stall of the host — a page
+            # fault storm, a collector pause — is tens of calls long at these sizes), the mean rides along
+            tp, tv = [], []
             for r in range(reps):
+                t0 = time.perf_counter()
                 pr = eng.prove_scenario(E.SC_SHUFFLE, [k], seed, m_cap=m_cap)
-            t_prove = (time.perf_counter() - t0) / reps
-            t0 = time.perf_counter()
+                tp.append(time.perf_counter() - t0)
             for r in range(reps):
+                t0 = time.perf_counter()
                 rc = eng.verify_scenario(E.SC_SHUFFLE, [k], pr.proof, pr.commitments, pr.publics)
-            t_verify = (time.perf_counter() - t0) / reps
+                tv.append(time.perf_counter() - t0)
+            t_prove, t_verify = float(np.median(tp)), float(np.median(tv))
             assert rc == 0
             row = {"curve": CURVES[curve], "k": k, "multipliers": 2 * (k - 1), "gpu_prove_ms": t_prove * 1e3, "gpu_verify_ms": t_verify * 1e3,
+                   "gpu_prove_ms_mean": float(np.mean(tp)) * 1e3, "gpu_verify_ms_mean": float(np.mean(tv)) * 1e3,
                    "gpu_prove_inside_prove_ms": pr.timing[0] * 1e3}
             if not args.no_cpu_baseline:
                 ref = O.r1cs_prove(curve, O.SC_SHUFFLE, [k], seed, 2048, m_cap=m_cap)

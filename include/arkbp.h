@@ -175,6 +175,12 @@ int bp_gens_fold_tables(bp_ctx* ctx, size_t count, int window_bits, size_t budge
  * are paid once, the window is wider (c = 20 at 2^21 terms: 13 mixed adds per term instead of 17-18) and the result needs no
  * doublings.  Skewed scalars (0/1 witness vectors) fall back to the ordinary schedule.  Results never depend on it. */
 int bp_gens_msm_tables(bp_ctx* ctx, size_t count, size_t* bytes_out);
+/* Optional: build the DIRECT WINDOW TABLES of the small-statement path now (d * 16^w * base for B, B_blinding and the first `count`
+ * generators of G and H, 60 KiB per base: count = 8192 is 1 GB) instead of inside the first small proof — e.g. before bp_gens_share,
+ * which hands them on (a ctx that shares generators without them builds its own copy on first use).  count is rounded down to what
+ * BP_TUNE_DIRECT_MAX and the installed generators allow; count = 0 frees them.  As with the other tables: rebuilding them (a larger
+ * count, other generators) on a ctx whose tables are shared is the owner's responsibility.  Results never depend on it. */
+int bp_gens_direct_tables(bp_ctx* ctx, size_t count, size_t* bytes_out);
 /* Integrity check of both kinds of precomputed tables: every entry is re-derived from its stored neighbours by the chain rule
  * (e * 2^(w*j) * P = (e-1) * 2^(w*j) * P + 2^(w*j) * P, next window = the doubled last entry; MSM rows: next row = 16 * row) with
  * mixed additions / doublings compared projectively, anchored at the resident generators; *bad_fold_entries / *bad_msm_rows (either

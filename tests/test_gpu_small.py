@@ -70,7 +70,7 @@ def test_direct_tables_limit_and_rebuild(oracle):
         ref = oracle.r1cs_prove(0, 3, [100, 0], SEED, 512, m_cap=8)
         assert e.prove_scenario(3, [100, 0], SEED, m_cap=8).proof == ref.proof
         runs, cap = e.direct_stats()
-        assert cap == 128 and runs >= 1 + 2 * 7      # one launch of commitments (3 MSMs), then L and R of 7 rounds
+        assert cap == 128 and runs == 3 + 5 + 2 * 7      # A_I, A_O, S in one launch, T_1, T_3 .. T_6 in one, then L and R of 7 rounds
         big = oracle.r1cs_prove(0, 3, [200, 0], SEED, 512, m_cap=8)     # padded 256 > 128
         assert e.prove_scenario(3, [200, 0], SEED, m_cap=8).proof == big.proof
         assert e.direct_stats()[0] == runs
@@ -84,6 +84,15 @@ def test_direct_tables_limit_and_rebuild(oracle):
         assert e.direct_stats()[1] == 256
         with pytest.raises(A.ArkbpError):
             e.set_tuning(DIRECT_MAX, (1 << 16) + 1)
+        # the explicit form: built ahead of the first proof (e.g. before bp_gens_share), freed with 0
+        assert e.gens_direct_tables(0) == 0 and e.direct_stats()[1] == 0
+        assert e.gens_direct_tables(64) == (2 + 2 * 64) * 64 * 15 * 64 and e.direct_stats()[1] == 64
+        runs3 = e.direct_stats()[0]
+        small = oracle.r1cs_prove(0, 3, [50, 0], SEED, 512, m_cap=8)
+        assert e.prove_scenario(3, [50, 0], SEED, m_cap=8).proof == small.proof       # padded 64: inside the tables as built
+        assert e.direct_stats() == (runs3 + 3 + 5 + 2 * 6, 64)                        # A_I, A_O, S + T_1, T_3..T_6 + L, R of 6 rounds
+        assert e.prove_scenario(3, [200, 0], SEED, m_cap=8).proof == big.proof        # padded 256: the next proof that needs more rebuilds them
+        assert e.direct_stats()[1] == 256
     finally:
         e.close()
 
