@@ -53,15 +53,22 @@ struct BaseSegs {
     // segment is base first + j * stride — the sharded prover's rank r owns the bases r, r + world, ..)
     u32 stride[MSM_MAXSEG];
 };
+// The segment's fields are SELECTED (compares against scalar registers), not indexed by the lane-varying segment number: indexing
+// the kernel-argument struct compiles to four dependent vector loads in front of every gather of the accumulate loops.
 __device__ __forceinline__ const u32* seg_base_ptr(const BaseSegs& s, u32 idx) {
     u32 w = 0;
     if (s.glv) idx >>= 1;
     if (s.fixed_c4) { w = idx >> s.tbits; idx &= (1u << s.tbits) - 1u; }
-    int k = 0;
+    const u32* ptr = s.ptr[0];
+    u32 start = s.start[0], sd = s.stride[0];
+    u64 rw = s.row_words[0];
 #pragma unroll
-    for (int j = 1; j < MSM_MAXSEG; j++) k += (j < s.nseg && idx >= s.start[j]) ? 1 : 0;
-    const u32 sd = s.stride[k] ? s.stride[k] : 1u;
-    return s.ptr[k] + (size_t)(idx - s.start[k]) * sd * 16 + (size_t)(w * s.fixed_c4) * s.row_words[k];
+    for (int j = 1; j < MSM_MAXSEG; j++) {
+        const bool in = j < s.nseg && idx >= s.start[j];
+        ptr = in ? s.ptr[j] : ptr; start = in ? s.start[j] : start; sd = in ? s.stride[j] : sd; rw = in ? s.row_words[j] : rw;
+    }
+    sd = sd ? sd : 1u;
+    return ptr + (size_t)(idx - start) * sd * 16 + (size_t)(w * s.fixed_c4) * rw;
 }
 
 // The scalar vector of an MSM, likewise: up to MSM_MAXSEG device-resident runs (e.g. blinding || a_L || a_R of a commitment,
@@ -98,6 +105,19 @@ __device__ __forceinline__ Aff load_aff_dev(const u32* p) {
     u32 w[16];
     load_words8(w, p);
     load_words8(w + 8, p + 8);
+    return aff_load_dev(w);
+}
+// the same in two steps: the 64 bytes as they lie in memory (a gather issued one loop iteration ahead must not be UNPACKED there —
+// the unpack would wait for it in front of the addition it is meant to hide behind), then the limbs
+struct Raw16 { uint4 a, b, c, d; };
+__device__ __forceinline__ Raw16 load_raw16(const u32* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    Raw16 r;
+    r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3];
+    return r;
+}
+__device__ __forceinline__ Aff aff_from_raw(const Raw16& r) {
+    const u32 w[16] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w, r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w};
     return aff_load_dev(w);
 }
 // Jacobian points in workspace: 3 x 8 words, canonical R' form; Z == 0 words <=> identity
@@ -579,15 +599,17 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
         // the gather of entry e+1 (entry word, then a 64-byte base somewhere in a table far larger than L2) is issued before the
         // mixed add of entry e, so its latency hides behind ~3 k VALU instructions instead of stalling the lane.  The first entry is
         // lifted, not added; the additions run the one-block form and redo the rare exceptional ones (ec.cuh jac_madd_fast).
+        // (the gather of e + 1 stays raw until the next iteration, and its entry word was read an iteration earlier still: neither
+        // the unpack nor the address computation waits on memory in front of the addition)
         u32 ent = entries[beg];
-        Aff p = load_aff_dev(seg_base_ptr(segs, ent >> 1));
+        u32 ent_n = beg + 1 < end ? entries[beg + 1] : 0u;
+        Raw16 raw = load_raw16(seg_base_ptr(segs, ent >> 1));
         for (u32 e = beg; e < end; e++) {
-            u32 ent_n = ent;
-            Aff p_n = p;
-            if (e + 1 < end) {
-                ent_n = entries[e + 1];
-                p_n = load_aff_dev(seg_base_ptr(segs, ent_n >> 1));
-            }
+            Raw16 raw_n = raw;
+            u32 ent_nn = 0;
+            if (e + 1 < end) raw_n = load_raw16(seg_base_ptr(segs, ent_n >> 1));
+            if (e + 2 < end) ent_nn = entries[e + 2];
+            const Aff p = aff_from_raw(raw);
             if (e == beg) {
                 acc = jac_from_aff<C>(aff_cneg_lazy<C>(p, ent & 1));
                 acc.Y = fe_wred<typename C::Fq>(acc.Y);
@@ -597,8 +619,8 @@ k_msm_accum(BaseSegs segs, const u32* __restrict__ entries, const u32* __restric
                 if (__builtin_expect(rare, 0)) nxt = jac_madd<C>(acc, aff_cneg_lazy<C>(load_aff_dev(seg_base_ptr(segs, ent >> 1)), ent & 1));
                 acc = nxt;
             }
-            ent = ent_n;
-            p = p_n;
+            ent = ent_n; ent_n = ent_nn;
+            raw = raw_n;
         }
     }
     store_jac_ws<C>(out + (size_t)j * 24, acc);
@@ -991,14 +1013,14 @@ k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __rest
     Jac acc = jac_inf<C>();
     if (beg < end) {
         u32 ent = entries[beg];
-        Aff p = load_aff_dev(seg_base_ptr(segs, ent >> 1));
-        for (u32 e = beg; e < end; e++) {
-            u32 ent_n = ent;
-            Aff p_n = p;
-            if (e + 1 < end) {
-                ent_n = entries[e + 1];
-                p_n = load_aff_dev(seg_base_ptr(segs, ent_n >> 1));
-            }
+        u32 ent_n = beg + 1 < end ? entries[beg + 1] : 0u;
+        Raw16 raw = load_raw16(seg_base_ptr(segs, ent >> 1));
+        for (u32 e = beg; e < end; e++) {   // (raw gather one entry ahead, entry word two ahead: see k_msm_accum)
+            Raw16 raw_n = raw;
+            u32 ent_nn = 0;
+            if (e + 1 < end) raw_n = load_raw16(seg_base_ptr(segs, ent_n >> 1));
+            if (e + 2 < end) ent_nn = entries[e + 2];
+            Aff p = aff_from_raw(raw);
             if constexpr (C::HAS_GLV) {   // odd half-terms of a split scalar stand for phi(base) = (beta * x, y)
                 if (segs.glv && (ent & 2u) && !aff_is_inf(p)) p.x = fe_mul<typename C::Fq>(p.x, fe_const<typename C::Fq, C::BETA29>());
             }
@@ -1017,8 +1039,8 @@ k_msm_accum_fs(BaseSegs segs, const u32* __restrict__ entries, const u32* __rest
                 }
                 acc = nxt;
             }
-            ent = ent_n;
-            p = p_n;
+            ent = ent_n; ent_n = ent_nn;
+            raw = raw_n;
         }
     }
     store_jac_ws<C>(out + (size_t)j * 24, acc);
