@@ -301,18 +301,24 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
             const u32* T = tables + (size_t)p * stride;
             const u32* Z = T + ((size_t)3 * (nlo + nhi) + nlo) * VT_W;   // z^e = Z[e & 255] * Z[256 + (e >> 8)]
             const u32* K = Z + (size_t)(256 + nzhi + 256) * VT_W;        // x, alpha, u, r*x
-            // next column entry in flight: its words, the two table entries of its power of z, its coefficient
+            // next column entry in flight: its words, the two table entries of its power of z, its coefficient.  The loads are
+            // UNCONDITIONAL (a unit coefficient reads entry 0 of the table and ignores it; the last entry of a column is requested
+            // twice): a conditional load merges with the old value in a register copy right behind the load, and that copy waits
+            // for the data in front of the products it was issued early to hide behind (seen in the ISA: `s_waitcnt vmcnt(1)`
+            // directly after the loads; 66 % of the issue slots used).  Entries beyond the VFY_EMAX that live in LDS take the plain
+            // loop at the end.
+            const u32 ne_fast = min(ne, VFY_EMAX);
             u32 ent_n = 0, cid_n = 0x80000000u, cw_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             Fe zl_n = fe_zero<F>(), zh_n = fe_zero<F>();
-            auto fetch = [&](u32 x) {
-                ent_n = x < VFY_EMAX ? es[x * 256u + tid] : t.m_ent[e0 + x];
-                cid_n = x < VFY_EMAX ? es[(VFY_EMAX + x) * 256u + tid] : t.m_c[e0 + x];
+            auto fetch = [&](u32 x) {   // x < ne_fast
+                ent_n = es[x * 256u + tid];
+                cid_n = es[(VFY_EMAX + x) * 256u + tid];
                 const u32 q = (ent_n & 0x3fffffffu) + 1u;
                 zl_n = load_fe_limbs(Z + (size_t)(q & 255u) * VT_W);
                 zh_n = load_fe_limbs(Z + (size_t)(256u + (q >> 8)) * VT_W);
-                if (!(cid_n & 0xc0000000u)) load_words8(cw_n, coefs + (size_t)cid_n * 8);
+                load_words8(cw_n, coefs + (size_t)((cid_n & 0xc0000000u) ? 0u : cid_n) * 8);
             };
-            if (ne) fetch(0);
+            if (ne_fast) fetch(0);
             // wc enters the B scalar with the same weight as delta: r * x^2 * (wc + delta) (verifier.rs:529); lanes share the terms;
             // wcp collects alpha * x * (their sum).  Computed first: its table reads share the round trip of the reads below, and
             // alpha * x * z^(q+1) = zx_lo[e & 255] * z_hi[e >> 8] is one product
@@ -347,23 +353,40 @@ k_vfy_batch(VfyTemplateDev t, const u32* __restrict__ params, const u32* __restr
                 // and weak reduction after every sixth entry (limbs of <= 7 summed L = 1 terms fit 32 bits).
                 Fe wL = fe_zero<F>(), wR = fe_zero<F>(), wO = fe_zero<F>(), zp = fe_one<F>();
                 u32 cur = 0, since = 0;   // exponent zp holds (0 = none yet; q + 1 >= 1 always)
-                for (u32 x = 0; x < ne; x++) {
-                    const u32 ent = ent_n, cid = cid_n;   // bit 31 of cid: the coefficient is +1, bit 30: it is -1 (most gadget constraints): no product
+                // one column entry: bit 31 of cid: the coefficient is +1, bit 30: it is -1 (most gadget constraints): no product.  exp_z for
+                // constraint q is z^(q+1) (verifier.rs:323-345).  (A macro, not a lambda: with the operands passed by reference the field
+                // elements went through scratch memory.)
+#define ARKBP_VFY_CONSUME(ent, cid, zl, zh, cw)                                                                                              \
+    {                                                                                                                                        \
+        const u32 q1 = ((ent) & 0x3fffffffu) + 1u, vec = (ent) >> 30;                                                                         \
+        if (q1 != cur) zp = fe_mul<F>(zl, zh);                                                                                               \
+        cur = q1;                                                                                                                            \
+        Fe term;                                                                                                                             \
+        if ((cid) & 0x80000000u) term = zp;                                                                                                  \
+        else if ((cid) & 0x40000000u) term = fe_neg<F, 2>(zp);                                                                               \
+        else term = fe_mul<F>(zp, fe_unpack(cw));                                                                                            \
+        if (vec == 0) wL = fe_add(wL, term); else if (vec == 1) wR = fe_add(wR, term); else wO = fe_add(wO, term);                           \
+        if (++since == 6) { wL = fe_wred<F>(fe_norm(wL)); wR = fe_wred<F>(fe_norm(wR)); wO = fe_wred<F>(fe_norm(wO)); since = 0; }           \
+    }
+                for (u32 x = 0; x < ne_fast; x++) {
+                    const u32 ent = ent_n, cid = cid_n;
                     const Fe zl = zl_n, zh = zh_n;
                     u32 cw[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) cw[j] = cw_n[j];
-                    if (x + 1 < ne) fetch(x + 1);
-                    const u32 q1 = (ent & 0x3fffffffu) + 1u, vec = ent >> 30;   // exp_z for constraint q is z^(q+1) (verifier.rs:323-345)
-                    if (q1 != cur) zp = fe_mul<F>(zl, zh);
-                    cur = q1;
-                    Fe term;
-                    if (cid & 0x80000000u) term = zp;
-                    else if (cid & 0x40000000u) term = fe_neg<F, 2>(zp);
-                    else term = fe_mul<F>(zp, fe_unpack(cw));
-                    if (vec == 0) wL = fe_add(wL, term); else if (vec == 1) wR = fe_add(wR, term); else wO = fe_add(wO, term);
-                    if (++since == 6) { wL = fe_wred<F>(fe_norm(wL)); wR = fe_wred<F>(fe_norm(wR)); wO = fe_wred<F>(fe_norm(wO)); since = 0; }
+                    fetch(min(x + 1u, ne_fast - 1u));
+                    ARKBP_VFY_CONSUME(ent, cid, zl, zh, cw)
                 }
+#pragma unroll 1
+                for (u32 x = ne_fast; x < ne; x++) {   // (a column with more than VFY_EMAX entries: rare)
+                    const u32 ent = t.m_ent[e0 + x], cid = t.m_c[e0 + x];
+                    const u32 q = (ent & 0x3fffffffu) + 1u;
+                    const Fe zl = load_fe_limbs(Z + (size_t)(q & 255u) * VT_W), zh = load_fe_limbs(Z + (size_t)(256u + (q >> 8)) * VT_W);
+                    u32 cw[8];
+                    load_words8(cw, coefs + (size_t)((cid & 0xc0000000u) ? 0u : cid) * 8);
+                    ARKBP_VFY_CONSUME(ent, cid, zl, zh, cw)
+                }
+#undef ARKBP_VFY_CONSUME
                 wL = fe_norm(wL); wR = fe_norm(wR); wO = fe_norm(wO);   // L = 1, V <= 2 + 6 * 3
                 // alpha * g = alpha*x*y^-i*wR - alpha*a*s[i];  alpha * h = alpha*y^-i * (x*wL + wO - b*s[N-1-i]) - alpha;
                 // alpha*r*x^2 * y^-i*wR*wL = (r*x) * (alpha*x*y^-i*wL) * wR   (verifier.rs:477-500, weighted by the batch's alpha)
