@@ -1131,7 +1131,7 @@ def run_headline(args, rank, world, local):
         leg("verify_cfg4_strong", run_verify, verify_strong=True, no_cpu_baseline=True)
     if world == 1 and not args.headline_only:
         # the other configurations of BASELINE.json on this one GPU (every config in the driver's line)
-        leg("cfg1", run_shuffle_sweep, sweep_ks=[2], sweep_one_curve=True, steps=20, warmup=3)                       # k = 2 shuffle, GPU beside the CPU restatement
+        leg("cfg1", run_shuffle_sweep, sweep_ks=[2, 64, 1024], sweep_one_curve=True, steps=20, warmup=3)             # k = 2 shuffle (cfg1) and two more rows of the reference's sweep, GPU beside the CPU restatement
         leg("msm", run_msm, terms=1 << 16, steps=200, warmup=20, shard="terms")                                      # cfg2
         # cfg3 on the zorro curve: no endomorphism there, so the fold tables are twice the size per window width and worth more (w = 5 / 84 GB
         # 14.0 M constraints/s, w = 7 / 238 GB 19.1 M): this leg may take 150 GB (w = 6)
