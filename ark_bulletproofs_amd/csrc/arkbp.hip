@@ -787,8 +787,9 @@ template <class C> static int msm_run(bp_ctx* ctx, const BaseSegs& segs, const u
             hipLaunchKernelGGL(k_msm_bin_sort, dim3(bp.NBIN, pl.W), dim3(256), (((size_t)1 << bp.LB) + 4 + bp.cap) * 4, st, ctx->slots.as<u32>(),
                                ctx->bin_cur.as<u32>(), ctx->hist.as<u32>(), ctx->boff.as<u32>(), pl, bp, sp);
         } else {
-            hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), 0, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont, sp,
-                               ctx->slots.as<u32>(), d_over);
+            const u32 lds_hist = gb == 1 && (size_t)pl.B <= 12288 ? (u32)pl.B : 0u;   // one workgroup: count in LDS (48 KiB of counters at most)
+            hipLaunchKernelGGL(k_msm_digits<C>, dim3(gb), dim3(TB), (size_t)lds_hist * 4, st, d_scalars, ctx->canon.as<u32>(), ctx->hist.as<u32>(), pl, scalars_mont, sp,
+                               ctx->slots.as<u32>(), d_over, lds_hist);
         }
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(256), 0, st, ctx->hist.as<u32>(), d_tiles, pl.B, nl, chl, b_gen, spl);
         hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(64), 0, st, d_tiles, ntiles, d_tot, lvl, pl.B);
