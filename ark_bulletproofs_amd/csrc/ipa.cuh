@@ -37,6 +37,39 @@ template <class F> __global__ void k_scalars_export(const u32* __restrict__ in, 
     store_words8(out + (size_t)i * 8, w);
 }
 
+// five vectors of ark-layout scalars in ONE launch (the witness of a small statement: a_L, a_R, a_O, s_L, s_R): `in` holds them back
+// to back ([5][n][8] words; pinned host memory read through the bus: no copy in front), out0 .. out4 receive the resident form.
+// Ten stream operations (five copies, five launches of ~4 us each plus their gaps) are ~100 us of a 500 us proof.
+template <class F> __global__ void k_scalars_import5(const u32* __restrict__ in, u32 n, u32* __restrict__ out0, u32* __restrict__ out1, u32* __restrict__ out2,
+                                                     u32* __restrict__ out3, u32* __restrict__ out4) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 5u * n) return;
+    const u32 v = t / n, i = t - v * n;
+    u32* out = v == 0 ? out0 : v == 1 ? out1 : v == 2 ? out2 : v == 3 ? out3 : out4;
+    u32 w[8];
+    load_words8(w, in + (size_t)t * 8);
+    store_fe_dev<F>(out + (size_t)i * 8, fe_load_ark<F>(w));
+}
+
+// several buffers zeroed by one launch (the witness-derived vectors at the end of a small proof: eleven memsets are eleven stream
+// operations).  n16[k]: 16-byte units of buffer k.
+static constexpr int ZERO_MAX = 12;
+struct ZeroList {
+    uint4* p[ZERO_MAX];
+    u32 n16[ZERO_MAX];
+    int count;
+};
+__global__ void __launch_bounds__(256) k_zero_many(ZeroList l) {
+    const u32 T = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < ZERO_MAX; k++) {
+        if (k >= l.count) break;
+        uint4* q = l.p[k];
+        const u32 n = l.n16[k];
+        for (u32 i = t0; i < n; i += T) q[i] = make_uint4(0, 0, 0, 0);
+    }
+}
+
 struct Words8 {
     u32 w[8];
 };
