@@ -313,7 +313,8 @@ struct bp_ctx {
     DevBuf dt_tab, dt_part, dt_a2, dt_b2, dt_ticket;
     size_t dt_cap = 0;
     size_t tune_direct_max = 8192;   // BP_TUNE_DIRECT_MAX: padded sizes up to this one prove over the direct tables (0 = never)
-    u32* h_dt = nullptr;             // pinned: the results of one launch
+    u32* h_dt = nullptr;             // pinned: the results of one launch (or its partial points, see msm_direct_launch)
+    u32 dt_pending_parts = 1;        // partial points per MSM on their way to h_dt
     uint64_t dt_runs = 0;            // MSMs answered from the direct tables
     IpaState ipa_step;         // bp_ipa_begin .. bp_ipa_finish
     bool ipa_step_active = false;
@@ -1580,6 +1581,7 @@ template <class C> static int dt_ensure(bp_ctx* ctx, size_t N, bool& ready) {
     ready = true;
     return BP_OK;
 }
+static constexpr u32 DT_HOST_SUM_MAX = 16;
 // nout MSMs over the direct tables in one launch (+ one finishing launch when more than one workgroup per MSM is worth it): the
 // launch half leaves the results on their way to pinned memory, the collect half reads them after the caller's stream wait
 template <class C> static int msm_direct_launch(bp_ctx* ctx, const DtJobs& jobs, int nout) {
@@ -1592,23 +1594,34 @@ template <class C> static int msm_direct_launch(bp_ctx* ctx, const DtJobs& jobs,
     u32 nblk = (u32)std::max<size_t>(1, (units + 63) / 64);
     if ((size_t)nblk * nout > 256) nblk = (u32)std::min<size_t>(1024, (units + 127) / 128);
     BPCHK(ctx->dt_part.ensure((size_t)DT_MAXOUT * (nblk + 1) * 96));
-    if (!ctx->h_dt) HIPCHK(hipHostMalloc((void**)&ctx->h_dt, DT_MAXOUT * 96));
+    if (!ctx->h_dt) HIPCHK(hipHostMalloc((void**)&ctx->h_dt, (size_t)DT_MAXOUT * DT_HOST_SUM_MAX * 96));
     u32* part = ctx->dt_part.as<u32>();
     u32* res = part + (size_t)DT_MAXOUT * nblk * 24;
+    // up to DT_HOST_SUM_MAX partial points per MSM are added by the HOST (0.4 us per addition there) instead of a second launch whose
+    // six-level tree costs ~35 us however few points it adds
+    const bool host_sum = nblk > 1 && nblk <= DT_HOST_SUM_MAX;
     {
         ScopedK tk(ctx, BP_K_MSM_ACCUM);
         hipLaunchKernelGGL(k_dt_accum<C>, dim3(nblk, (u32)nout), dim3(256), 0, st, ctx->dt_tab.as<u32>(), jobs, nblk == 1 ? res : part);
-        if (nblk > 1) hipLaunchKernelGGL(k_dt_finish<C>, dim3((u32)nout), dim3(256), 0, st, part, nblk, res);
+        if (nblk > 1 && !host_sum) hipLaunchKernelGGL(k_dt_finish<C>, dim3((u32)nout), dim3(256), 0, st, part, nblk, res);
     }
-    HIPCHK(hipMemcpyAsync(ctx->h_dt, res, (size_t)nout * 96, hipMemcpyDeviceToHost, st));
+    ctx->dt_pending_parts = host_sum ? nblk : 1u;
+    HIPCHK(hipMemcpyAsync(ctx->h_dt, host_sum ? part : res, (size_t)nout * ctx->dt_pending_parts * 96, hipMemcpyDeviceToHost, st));
     return BP_OK;
 }
 template <class C> static void msm_direct_collect(bp_ctx* ctx, int nout, J4* results) {
     typedef host::Grp<C> G;
     const u64* T = (const u64*)ctx->h_dt;
+    const u32 np = ctx->dt_pending_parts;
     for (int o = 0; o < nout; o++) {
-        J4 pnt; memcpy(pnt.X.v, T + 12 * o, 32); memcpy(pnt.Y.v, T + 12 * o + 4, 32); memcpy(pnt.Z.v, T + 12 * o + 8, 32);
-        results[o] = pnt.Z.is_zero() ? G::inf() : pnt;
+        J4 acc = G::inf();
+        for (u32 j = 0; j < np; j++) {
+            const u64* P = T + 12 * ((size_t)o * np + j);
+            J4 pnt; memcpy(pnt.X.v, P, 32); memcpy(pnt.Y.v, P + 4, 32); memcpy(pnt.Z.v, P + 8, 32);
+            if (pnt.Z.is_zero()) continue;
+            acc = np == 1 ? pnt : G::add(acc, pnt);
+        }
+        results[o] = acc;
     }
     ctx->dt_runs += (uint64_t)nout;
 }

@@ -448,6 +448,12 @@ template <class C> struct PedersenGens {
         }
         return acc;
     }
+    // the same before the final inversion (several commitments share one: Montgomery's trick at the caller)
+    J4 commit_jac(const F4& v, const F4& blind) const {
+        const FixedTables& ft = fixed_tables();
+        if (B == ft.B && B_blinding == ft.Bb) return fixed_mul_acc(fixed_mul_acc(Grp<C>::inf(), ft.tB, v), ft.tBb, blind);
+        return Grp<C>::add(Grp<C>::mul(B, v), Grp<C>::mul(B_blinding, blind));
+    }
     A4 commit(const F4& v, const F4& blind) const {  // src/generators.rs:39-44
         const FixedTables& ft = fixed_tables();
         if (B == ft.B && B_blinding == ft.Bb) return Grp<C>::to_aff(fixed_mul_acc(fixed_mul_acc(Grp<C>::inf(), ft.tB, v), ft.tBb, blind));
