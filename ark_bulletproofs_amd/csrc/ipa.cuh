@@ -37,15 +37,25 @@ template <class F> __global__ void k_scalars_export(const u32* __restrict__ in, 
     store_words8(out + (size_t)i * 8, w);
 }
 
-// five vectors of ark-layout scalars in ONE launch (the witness of a small statement: a_L, a_R, a_O, s_L, s_R): `in` holds them back
-// to back ([5][n][8] words; pinned host memory read through the bus: no copy in front), out0 .. out4 receive the resident form.
-// Ten stream operations (five copies, five launches of ~4 us each plus their gaps) are ~100 us of a 500 us proof.
-template <class F> __global__ void k_scalars_import5(const u32* __restrict__ in, u32 n, u32* __restrict__ out0, u32* __restrict__ out1, u32* __restrict__ out2,
-                                                     u32* __restrict__ out3, u32* __restrict__ out4) {
+// several vectors of ark-layout scalars in ONE launch (the witness of a small statement: a_L, a_R, a_O, s_L, s_R; its coefficient
+// table and the power tables of y and z): `in` holds them back to back (8 words per scalar; pinned host memory read through the
+// bus: no copy in front), dst[k] receives the resident form of the cnt[k] scalars of vector k.  Ten stream operations (five copies,
+// five launches of ~4 us each plus their gaps) are ~100 us of a 500 us proof.
+static constexpr int IMPORT_MAX = 5;
+struct ImportList {
+    u32* dst[IMPORT_MAX];
+    u32 cnt[IMPORT_MAX];
+    int nseg;
+};
+template <class F> __global__ void k_scalars_import_multi(const u32* __restrict__ in, ImportList l) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 5u * n) return;
-    const u32 v = t / n, i = t - v * n;
-    u32* out = v == 0 ? out0 : v == 1 ? out1 : v == 2 ? out2 : v == 3 ? out3 : out4;
+    u32 i = t;
+    u32* out = nullptr;
+#pragma unroll
+    for (int k = 0; k < IMPORT_MAX; k++) {
+        if (k < l.nseg && !out) { if (i < l.cnt[k]) out = l.dst[k]; else i -= l.cnt[k]; }
+    }
+    if (!out) return;
     u32 w[8];
     load_words8(w, in + (size_t)t * 8);
     store_fe_dev<F>(out + (size_t)i * 8, fe_load_ark<F>(w));

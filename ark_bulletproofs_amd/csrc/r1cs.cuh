@@ -24,7 +24,8 @@ template <class F> __device__ __forceinline__ Fe pow_from_table(const u32* __res
 template <class C> __global__ void __launch_bounds__(256)
 k_r1cs_poly_t(const u32* __restrict__ aL, const u32* __restrict__ aR, const u32* __restrict__ aO, const u32* __restrict__ sL,
               const u32* __restrict__ sR, const u32* __restrict__ wL, const u32* __restrict__ wR, const u32* __restrict__ wO,
-              const u32* __restrict__ ypow, u32 n, u32* __restrict__ partials) {
+              const u32* __restrict__ ypow, u32 n, u32* __restrict__ partials, u32* __restrict__ final_ark = nullptr /* one workgroup: the six sums
+              in ark words, as k_r1cs_sum would leave them (a small statement saves that launch) */) {
     typedef typename C::Fr F;
     __shared__ u32 sh[9 * 256];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -49,7 +50,10 @@ k_r1cs_poly_t(const u32* __restrict__ aL, const u32* __restrict__ aR, const u32*
 #pragma unroll   // (a rolled loop indexes t[] dynamically and sends the six accumulators through scratch: 440 MB of writes at N = 2^20)
     for (int k = 0; k < 6; k++) {
         Fe s = block_sum_fe<F>(fe_wred<F>(t[k]), sh);
-        if (threadIdx.x == 0) store_fe_dev<F>(partials + ((size_t)blockIdx.x * 6 + k) * 8, s);
+        if (threadIdx.x == 0) {
+            if (final_ark) { u32 w[8]; fe_store_ark<F>(w, s); store_words8(final_ark + (size_t)k * 8, w); }
+            else store_fe_dev<F>(partials + ((size_t)blockIdx.x * 6 + k) * 8, s);
+        }
     }
 }
 // out: cnt x 8 words, ark Montgomery layout (read by the host)
