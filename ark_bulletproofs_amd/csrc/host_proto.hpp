@@ -834,11 +834,15 @@ template <class C> static int scenario_prover(ConstraintSystem<C>& cs, const Ped
             for (auto& x : in) x = S::from_u64(prng.next_u64());
             for (size_t i = 0; i < k; i++) out[i] = in[(i + 1) % k];
             cs.tr->append_message("dom-sep", "ShuffleProof"); cs.tr->append_u64("k", k);
-            std::vector<Var> xv, yv;
-            for (size_t i = 0; i < k; i++) bl[i] = rand_fe<FrP>(prng);
-            int rc = commit_many(in, bl, xv); if (rc) return rc;
-            for (size_t i = 0; i < k; i++) bl[i] = rand_fe<FrP>(prng);
-            rc = commit_many(out, bl, yv); if (rc) return rc;
+            // Prover::commit for the k inputs, then the k outputs (benches/r1cs_secq256k1.rs:160-175): the points do not depend on each
+            // other, so all 2k go to the engine as ONE batch; the blinding draws, the transcript appends and the variable numbering
+            // keep the reference's order
+            std::vector<F4> vals(2 * k), bls(2 * k);
+            for (size_t i = 0; i < k; i++) { vals[i] = in[i]; bls[i] = rand_fe<FrP>(prng); }
+            for (size_t i = 0; i < k; i++) { vals[k + i] = out[i]; bls[k + i] = rand_fe<FrP>(prng); }
+            std::vector<Var> all;
+            int rc = commit_many(vals, bls, all); if (rc) return rc;
+            std::vector<Var> xv(all.begin(), all.begin() + k), yv(all.begin() + k, all.end());
             return shuffle_gadget<C>(cs, xv, yv);
         }
         case SC_RANGE: {
