@@ -214,6 +214,7 @@ struct IpaState {
     // tables for one more round, and the second fold produces Ghat'' / Hhat'' straight from the tables
     bool deferred = false;
     F4 def_tG, def_tH;
+    size_t min_len = 0;         // index-cyclic slices: the local length at which the ranks gather (a deferred fold needs one more local round)
     bool direct = false;        // frozen from round 1 over the ctx's generator tables, L and R as sums over the direct window tables (small.cuh)
     // direct: the fold a challenge asks for is carried out by the NEXT round's k_dt_round (or by k_ipa_fold_ab after the last round)
     bool fold_pending = false;
@@ -316,6 +317,7 @@ struct bp_ctx {
     u32* h_dt = nullptr;             // pinned: the results of one launch (or its partial points, see msm_direct_launch)
     u32 dt_pending_parts = 1;        // partial points per MSM on their way to h_dt
     uint64_t dt_runs = 0;            // MSMs answered from the direct tables
+    uint64_t folds_deferred = 0, folds_tab2 = 0;   // first folds deferred / second folds that came straight from the tables (bp_ctx_fold_stats)
     IpaState ipa_step;         // bp_ipa_begin .. bp_ipa_finish
     bool ipa_step_active = false;
     u32* h_totals = nullptr;  // pinned
@@ -1522,8 +1524,13 @@ template <class C> static int launch_tab_fold(bp_ctx* ctx, const IpaState& s, u3
 // round nor the next reaches the frozen-tail length
 template <class C> static bool fold_can_defer(bp_ctx* ctx, const IpaState& s, size_t n, const F4& tG1, const F4& tH1) {
     static const bool off = getenv("ARKBP_FOLD_NODEFER") != nullptr || getenv("ARKBP_FOLD_NOTAB") != nullptr;   // A/B switches
-    if (off || !ctx->ftab_n || !s.d_G_in || !s.d_H_in || s.gens_stride != 1 || s.gens_first != 0 || ctx->shard_world > 1 || s.msm_mode != -1) return false;
-    if (n < 256 || (n & 1) || n + n / 2 > ctx->ftab_n) return false;
+    if (off || !ctx->ftab_n || !s.d_G_in || !s.d_H_in || !s.gens_stride) return false;
+    // either the whole vectors on one GPU, or this rank's index-cyclic slice (local element j = table base first + j * stride; its
+    // MSMs are partial sums followed by the point-reduce) with one more LOCAL round to come
+    const bool whole = s.gens_stride == 1 && s.gens_first == 0 && ctx->shard_world == 1 && s.msm_mode == -1;
+    const bool slice = s.msm_mode == 2 && ctx->shard_world > 1 && s.first && n > s.min_len;
+    if (!whole && !slice) return false;
+    if (n < 256 || (n & 1) || (size_t)s.gens_first + (n + n / 2 - 1) * (size_t)s.gens_stride >= ctx->ftab_n) return false;
     if (s.allow_freeze && n / 2 <= std::max<size_t>(ctx->tune_ipa_freeze_len, 2)) return false;
     if (!s.have_rho) return false;
     FtabDigits d;
@@ -1542,7 +1549,7 @@ template <class C> static int launch_tab_fold2(bp_ctx* ctx, const IpaState& s, u
     {
         ScopedK tk(ctx, BP_K_FOLD_TAB);
         hipLaunchKernelGGL(k_ipa_fold_tab2<C>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, ctx->ftab_G.as<u32>(), ctx->ftab_H.as<u32>(), (u32)ctx->ftab_n,
-                           1u << (ctx->ftab_w - 1), d_G, d_H, (u32)m, dG, dH, ff.jac, s.d_G_in, s.d_H_in);
+                           1u << (ctx->ftab_w - 1), d_G, d_H, (u32)m, dG, dH, ff.jac, s.d_G_in, s.d_H_in, s.gens_first, s.gens_stride);
     }
     fold_finish_launch<C>(ctx, ff, d_G, d_H, m, 3, lanes);
     done = true;
@@ -1739,8 +1746,42 @@ template <class C> static int ipa_round_lr(bp_ctx* ctx, IpaState& s, uint64_t Lw
                                words_of<S>(s.gamma_G), words_of<S>(s.gamma_H), s.d_rho_pow, words_of<S>(s.def_tG), words_of<S>(s.def_tH));
             hipLaunchKernelGGL(k_ipa_ip_finish<C>, dim3(1), dim3(256), 0, st, ctx->ipa_part.as<u32>(), gb, sL + 4 * n * 8, sR + 4 * n * 8, words_of<S>(s.qw), s.have_qw ? 1 : 0);
         }
-        const size_t gofs = (size_t)(s.d_G_in - ctx->d_G.as<u32>()) / 16, hofs = (size_t)(s.d_H_in - ctx->d_H.as<u32>()) / 16;
         J4 Lj, Rj; bool dl = false, dr = false;
+        if (s.msm_mode == 2) {
+            // this rank's index-cyclic slice (the working vectors are its compact copy, local element j = table base first + j * stride):
+            // the same four runs read the fixed-base rows with a stride; every MSM ends in exactly one point-reduce, whichever way it ran
+            BaseSegs sg; memset(&sg, 0, sizeof sg);
+            sg.nseg = 5;
+            for (int k = 0; k <= 4; k++) sg.start[k] = (u32)(k * n);
+            sg.start[5] = (u32)(4 * n + 1);
+            const size_t f0 = s.gens_first, sd = s.gens_stride;
+            const bool rows = s.have_qw && ctx->fb_cap;
+            ScalSegs ss; memset(&ss, 0, sizeof ss);
+            ss.nseg = 2; ss.ptr[0] = sL; ss.start[0] = 0; ss.start[1] = (u32)(4 * n); ss.ptr[1] = sL + (4 * n + 1) * 8; ss.start[2] = (u32)(4 * n + 1);
+            if (rows) {
+                FbRun rl[5] = {{0, f0 + (n1 + n) * sd, n, sd}, {0, f0 + n * sd, n, sd}, {1, f0 + n1 * sd, n, sd}, {1, f0, n, sd}, {2, 0, 1}};
+                BPCHK(msm_fixed_run<C>(ctx, rl, 5, ss, 4 * n + 1, 0, Lj, dl, 2));
+            }
+            if (!dl) {
+                sg.ptr[0] = s.d_G_in + (n1 + n) * 16; sg.ptr[1] = s.d_G_in + n * 16; sg.ptr[2] = s.d_H_in + n1 * 16; sg.ptr[3] = s.d_H_in; sg.ptr[4] = s.d_Q;
+                BPCHK(msm_run<C>(ctx, sg, sL, 4 * n + 1, 0, Lj, 0, -1, 2));
+            }
+            if (rows) {
+                ss.ptr[0] = sR; ss.ptr[1] = sR + (4 * n + 1) * 8;
+                FbRun rr[5] = {{0, f0 + n1 * sd, n, sd}, {0, f0, n, sd}, {1, f0 + (n1 + n) * sd, n, sd}, {1, f0 + n * sd, n, sd}, {2, 0, 1}};
+                BPCHK(msm_fixed_run<C>(ctx, rr, 5, ss, 4 * n + 1, 0, Rj, dr, 2));
+            }
+            if (!dr) {
+                sg.ptr[0] = s.d_G_in + n1 * 16; sg.ptr[1] = s.d_G_in; sg.ptr[2] = s.d_H_in + (n1 + n) * 16; sg.ptr[3] = s.d_H_in + n * 16; sg.ptr[4] = s.d_Q;
+                BPCHK(msm_run<C>(ctx, sg, sR, 4 * n + 1, 0, Rj, 0, -1, 2));
+            }
+            A4 La = G::to_aff(Lj), Ra = G::to_aff(Rj);
+            memcpy(Lw, La.x.v, 32); memcpy(Lw + 4, La.y.v, 32);
+            memcpy(Rw, Ra.x.v, 32); memcpy(Rw + 4, Ra.y.v, 32);
+            s.lr_done = true;
+            return BP_OK;
+        }
+        const size_t gofs = (size_t)(s.d_G_in - ctx->d_G.as<u32>()) / 16, hofs = (size_t)(s.d_H_in - ctx->d_H.as<u32>()) / 16;
         if (s.have_qw && s.msm_mode == -1) {
             ScalSegs ss; memset(&ss, 0, sizeof ss);
             ss.nseg = 2; ss.ptr[0] = sL; ss.start[0] = 0; ss.start[1] = (u32)(4 * n); ss.ptr[1] = sL + (4 * n + 1) * 8; ss.start[2] = (u32)(4 * n + 1);
@@ -1846,6 +1887,7 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
     // resident generator tables and needs no copy)
     auto working_copy = [&]() -> int {
         if (!s.d_G_in) return BP_OK;
+        if (s.d_G_in == s.d_G) { s.d_G_in = s.d_H_in = nullptr; return BP_OK; }   // (an index-cyclic slice: the working vectors ARE the compact copy)
         HIPCHK(hipMemcpyAsync(s.d_G, s.d_G_in, 2 * n * 64, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(s.d_H, s.d_H_in, 2 * n * 64, hipMemcpyDeviceToDevice, st));
         s.d_G_in = s.d_H_in = nullptr;
@@ -1890,6 +1932,7 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
                 // and its fold (below, `s.deferred`) computes Ghat'' / Hhat'' directly
                 s.deferred = true; s.def_tG = tG1; s.def_tH = tH1;
                 tab_done = true;
+                ctx->folds_deferred++;
             } else
             BPCHK(launch_tab_fold<C>(ctx, s, d_G, d_H, n, tG1, tH1, tab_done));   // the bases are the generator tables themselves: fixed-base look-ups
             if (!tab_done) { BPCHK(working_copy()); BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, tG1, tH1, 3)); }
@@ -1924,12 +1967,15 @@ template <class C> static int ipa_round_fold(bp_ctx* ctx, IpaState& s, const uin
             if (s.deferred) {
                 bool done2 = false;
                 BPCHK(launch_tab_fold2<C>(ctx, s, d_G, d_H, n, t2G, t2H, done2));
+                if (done2) ctx->folds_tab2++;
                 if (!done2) {   // (a multiplier whose digits do not fit: materialise round 1 after all, then the ladder)
                     bool done1 = false;
                     BPCHK(launch_tab_fold<C>(ctx, s, d_G, d_H, 2 * n, s.def_tG, s.def_tH, done1));
                     if (!done1) {
+                        if (s.d_G_in != d_G) {
                         HIPCHK(hipMemcpyAsync(d_G, s.d_G_in, 4 * n * 64, hipMemcpyDeviceToDevice, st));
                         HIPCHK(hipMemcpyAsync(d_H, s.d_H_in, 4 * n * 64, hipMemcpyDeviceToDevice, st));
+                        }
                         BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, 2 * n, s.def_tG, s.def_tH, 3));
                     }
                     BPCHK(launch_uniform_fold<C>(ctx, d_G, d_H, n, t2G, t2H, 3));
@@ -2066,6 +2112,8 @@ static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const
                            ctx->cyc_b.as<u32>(), n_loc, gf_halves, geo ? rho_loc : nullptr, geo ? d_rho_pow + (size_t)w * 8 : nullptr, false));
     s.msm_mode = 2;
     s.gens_first = (u32)r; s.gens_stride = (u32)W;
+    s.d_G_in = s.d_G; s.d_H_in = s.d_H;   // round 1 reads the slice where it lies (and may defer its fold: two rounds from the tables, as on one GPU)
+    s.min_len = S_loc;
     if (qw) { s.qw = *qw; s.have_qw = true; }
     F4 rho_r = S::one(), rho_mr = S::one();   // rho^rank, rho^-rank
     if (geo) for (int k = 0; k < w; k++) if ((r >> k) & 1) { rho_r = S::mul(rho_r, rho_pw[32 + k]); rho_mr = S::mul(rho_mr, rho_pw[k]); }
@@ -3494,6 +3542,12 @@ int bp_debug_verify_challenges(int curve, size_t count, const int* scenarios, co
     if (!count || count > 8 || !scenarios || !params || !proofs || !proof_lens || !commit_xy || !ms || !publics || !npubs || !out || !nchal) return BP_E_ARG;
     return curve == 0 ? dbg_verify_challenges<Secq>(count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, use_x8, out, nchal)
                       : dbg_verify_challenges<Zorro>(count, scenarios, params, proofs, proof_lens, commit_xy, ms, publics, npubs, use_x8, out, nchal);
+}
+int bp_ctx_fold_stats(bp_ctx* c, uint64_t* deferred_first_folds, uint64_t* second_folds_from_tables) {
+    if (!c) return BP_E_ARG;
+    if (deferred_first_folds) *deferred_first_folds = c->folds_deferred;
+    if (second_folds_from_tables) *second_folds_from_tables = c->folds_tab2;
+    return BP_OK;
 }
 int bp_ctx_direct_stats(bp_ctx* c, uint64_t* direct_msms, size_t* bases_per_vector) {
     if (!c) return BP_E_ARG;

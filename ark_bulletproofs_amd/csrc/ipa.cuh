@@ -669,7 +669,8 @@ struct FtabDigits3 {
 // per proof, measured as 0.66 GB of HBM writes in the first version of this kernel.
 template <class C> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 k_ipa_fold_tab2(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_tab, u32 E, u32* __restrict__ G, u32* __restrict__ H, u32 m, FtabDigits3 dG,
-                FtabDigits3 dH, u32* __restrict__ jac_ws, const u32* __restrict__ Gin, const u32* __restrict__ Hin) {
+                FtabDigits3 dH, u32* __restrict__ jac_ws, const u32* __restrict__ Gin, const u32* __restrict__ Hin,
+                u32 g_first /* table base of local element j: g_first + j * g_stride (an index-cyclic slice; 0, 1 otherwise) */, u32 g_stride) {
     typedef typename C::Fq F;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * m) return;
@@ -680,7 +681,7 @@ k_ipa_fold_tab2(const u32* __restrict__ TG, const u32* __restrict__ TH, u32 n_ta
     Jac acc = jac_inf<C>();
 #pragma unroll 1
     for (u32 mu = 0; mu < 3; mu++) {
-        const u32 gi = mu == 0 ? m + i : mu == 1 ? n + i : i;        // t1 * Base[m+i] + t2 * Base[n+i] + t1*t2 * Base[i]
+        const u32 gi = g_first + (mu == 0 ? m + i : mu == 1 ? n + i : i) * g_stride;        // t1 * Base[m+i] + t2 * Base[n+i] + t1*t2 * Base[i]
         const u32 nwin = isH ? dH.d[mu].nwin : dG.d[mu].nwin;
         const unsigned long long neg1 = isH ? dH.d[mu].neg1 : dG.d[mu].neg1, neg2 = isH ? dH.d[mu].neg2 : dG.d[mu].neg2;
 #pragma unroll 1

@@ -996,3 +996,13 @@ def _gens_direct_tables(self, count):
 
 
 Engine.gens_direct_tables = _gens_direct_tables
+
+
+def _fold_stats(self):
+    """(first folds deferred, second folds produced straight from the fold tables) — the two-rounds-from-the-tables schedule"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    check(lib().bp_ctx_fold_stats(self.ctx, C.byref(a), C.byref(b)), "bp_ctx_fold_stats")
+    return a.value, b.value
+
+
+Engine.fold_stats = _fold_stats

@@ -540,7 +540,8 @@ def run_prove(args, rank, world, local):
         if args.fold_table_budget_gb > 0:
             budget = min(budget, int(args.fold_table_budget_gb * 1e9))
         # bases [0, 3N/4): the first TWO fold rounds come straight from the tables (bases [0, N/2) would serve the first round only)
-        tab_count = N * 3 // 4 if (args.fold_tables >= 2 and not window_sharded) else N // 2
+        # (the index-cyclic slices of a sharded prover defer their first fold the same way since round 4: same tables)
+        tab_count = N * 3 // 4 if args.fold_tables >= 2 else N // 2
         wbits, nbytes = engs[0].gens_fold_tables(tab_count, window_bits=args.fold_table_bits, budget_bytes=max(budget, 1 << 30))
         tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0, "bases": tab_count, "rounds_from_tables": 2 if tab_count > N // 2 else 1}
     for e in engs[1:]:

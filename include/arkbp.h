@@ -497,6 +497,10 @@ int bp_ctx_msm_stats(bp_ctx* ctx, uint64_t* fixed_base_runs, uint64_t* fixed_bas
 /* The small-statement path (BP_TUNE_DIRECT_MAX): MSMs this ctx answered from its direct window tables, and the number of generators
  * per vector those tables cover (0 = not built yet) */
 int bp_ctx_direct_stats(bp_ctx* ctx, uint64_t* direct_msms, size_t* bases_per_vector);
+/* Two fold rounds from the tables (bp_gens_fold_tables over 3N/4 bases; src/inner_product_proof.rs:143-155, 219-224): first folds this
+ * ctx deferred, and second folds it then produced straight from the tables — on one GPU and, since round 4, on the index-cyclic slice
+ * of a sharded prover */
+int bp_ctx_fold_stats(bp_ctx* ctx, uint64_t* deferred_first_folds, uint64_t* second_folds_from_tables);
 /* A ctx WITHOUT a device for sanitizer runs of the host layer on machines with no GPU (tools/sanitize/): only bp_r1cs_batch_verify,
  * bp_r1cs_batch_verify_scenarios, bp_ctx_set_tuning and bp_ctx_destroy accept it.  They run the complete host side of batch
  * verification — framing, square roots (on the host here), thread pools, shared recordings, transcript replay (live and lockstep),

@@ -190,7 +190,8 @@ def test_window_sharded_prover_ranks_as_threads(oracle, world):
                 assert proof == ref.proof and rc == 0 and rc_bad in (-4, -6)
 
 
-def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
+@pytest.mark.parametrize("two_rounds", [False, True])
+def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads(two_rounds):
     """cfg5's partition at full-size kernels with the default thresholds: a 2^16-constraint proof by two ranks (threads, one Engine
     each on the same GPU): Pippenger windows of the commitment MSMs partitioned, the IPA index-cyclic (32768 elements per rank,
     gather at 1024), the verifier's mega-check window-sharded.  Both ranks must emit exactly the single-GPU proof."""
@@ -208,7 +209,9 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
     # the ranks share the first-round fold tables and the fixed-base MSM rows too: the cyclic slices index both with a stride, the
     # commitments take the fixed-base schedule over per-rank blocks of the terms (round 4: the sharded prover keeps the single-GPU
     # MSM algorithm; BP_TUNE_MSM_FIXED_MIN lowered on every rank so that 2^16 reaches it): same proofs
-    single.gens_fold_tables(N // 2, window_bits=4)
+    # two_rounds: fold tables over 3N/4 bases — every rank DEFERS the first fold of its slice and takes its second fold straight from
+    # the tables, the round in between runs its L / R over the slice with split scalars (the single-GPU schedule of round 3, on slices)
+    single.gens_fold_tables(N * 3 // 4 if two_rounds else N // 2, window_bits=4)
     single.gens_msm_tables(N)
     single.set_tuning(5, 4096)
     for (sc, prm), ref in zip(cases, refs):
@@ -239,6 +242,7 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
                 got.append((pr.proof, e.verify_scenario(sc, prm, pr.proof, pr.commitments, pr.publics)))
             out[rank] = got
             fb_sharded[rank] = e.msm_stats()[1]
+            fold_stats[rank] = e.fold_stats()
             P.enable_window_sharding(e, cv, E.host_points_sum, 0, 1)
             e.close()
         except Exception as ex:
@@ -246,6 +250,7 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
             bar.abort()
 
     fb_sharded = [0] * world
+    fold_stats = [None] * world
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
@@ -260,6 +265,8 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads():
         # back to the ordinary MSM over ITS block / slice: the ranks still meet in one reduce per MSM, which is what this run checks;
         # the schedule itself is asserted at 2^22 in tests/test_gpu_fullsize.py)
         assert fb_sharded[r] >= 0
+        # one deferred first fold and one second fold from the tables per proof and rank — or none with tables for one round only
+        assert fold_stats[r] == ((len(cases), len(cases)) if two_rounds else (0, 0)), fold_stats[r]
     single.close()
 
 
