@@ -25,7 +25,7 @@ EXPORTS = [
     "bp_cs_specify_randomized_constraints", "bp_cs_challenge_scalar", "bp_prover_set_rng", "bp_prover_precompute", "bp_prover_precompute_batch", "bp_prover_prove",
     "bp_ctx_set_shard_allgather", "bp_gens_fold_tables", "bp_gens_msm_tables", "bp_debug_exp_iter", "bp_debug_inner_product", "bp_verifier_verify", "bp_r1cs_batch_verify", "bp_stmt_as_prover", "bp_transcript_export_state", "bp_transcript_import_state", "bp_transcript_clone",
     "bp_gens_tables_check", "bp_debug_tables_ptr", "bp_rccl_unique_id", "bp_ctx_rccl_init", "bp_ctx_rccl_shutdown", "bp_ctx_collective_stats", "bp_debug_rccl_allgather",
-    "bp_debug_vfe_schedule_replay", "bp_debug_vfe_challenges", "bp_ctx_vfe_stats", "bp_debug_verify_challenges", "bp_debug_ctx_create_hostonly", "bp_ctx_msm_stats", "bp_ctx_direct_stats", "bp_gens_direct_tables", "bp_ctx_fold_stats",
+    "bp_debug_vfe_schedule_replay", "bp_debug_vfe_challenges", "bp_ctx_vfe_stats", "bp_debug_verify_challenges", "bp_debug_ctx_create_hostonly", "bp_ctx_msm_stats", "bp_ctx_direct_stats", "bp_gens_direct_tables", "bp_ctx_fold_stats", "bp_gens_fold_tables_slice",
 ]
 
 

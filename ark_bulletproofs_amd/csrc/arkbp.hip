@@ -308,6 +308,7 @@ struct bp_ctx {
     // fixed-base tables of the generators for the first fold round (bp_gens_fold_tables; ipa.cuh k_ipa_fold_tab)
     DevBuf ftab_G, ftab_H;
     size_t ftab_n = 0;       // bases covered: G[0..ftab_n), H[0..ftab_n)
+    u32 ftab_first = 0, ftab_stride = 1;   // ... or, for a rank's SLICE of the tables (bp_gens_fold_tables_slice): column i = generator ftab_first + i * ftab_stride
     int ftab_w = 0, ftab_nwin = 0;
     // direct window tables of the first generators (small.cuh): bases [B, B_blinding | G[0..dt_cap) | H[0..dt_cap)], built on the first
     // small statement this ctx proves
@@ -1422,6 +1423,15 @@ static void ftab_recode(const uint64_t* mag, int nl, bool negate, int w, int nwi
     }
 }
 template <class C> static int ftab_nwin_for(int w) { return (C::HAS_GLV ? 130 : 256) / w + 1; }
+// element j of a rank's index-cyclic slice of a vector: in[rank + j * world] (32-byte scalars, 64-byte points)
+template <class W8> __global__ void k_cyclic_gather(const u32* __restrict__ in, u32* __restrict__ out, u32 n_loc, u32 rank, u32 world) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_loc) return;
+    const W8* src = (const W8*)in + ((size_t)rank + (size_t)j * world);
+    ((W8*)out)[j] = *src;
+}
+struct Blk32 { uint4 a, b; };
+struct Blk64 { uint4 a, b, c, d; };
 template <class C> static bool ftab_digits(const bp_ctx* ctx, const F4& t, FtabDigits& d) {
     typedef host::Fld<typename C::Fr> S;
     memset(&d, 0, sizeof d);
@@ -1440,11 +1450,14 @@ template <class C> static bool ftab_digits(const bp_ctx* ctx, const F4& t, FtabD
 }
 // Builds the tables for G[0..n), H[0..n) of the installed generators.  w = 0: the widest window (<= 8 bits) whose tables fit in
 // `budget_bytes` (0 = 3/4 of the free device memory).
-template <class C> static int ftab_build(bp_ctx* ctx, size_t n, int w, size_t budget_bytes) {
+// first / stride: the tables of the generators first + i * stride, i < n — 1/world of the memory for a rank of a sharded prover whose
+// inner-product argument works on that index-cyclic slice (these are the ctx's own tables then, whoever owns the generators).
+template <class C> static int ftab_build(bp_ctx* ctx, size_t n, int w, size_t budget_bytes, u32 first = 0, u32 stride = 1) {
     hipStream_t st = ctx->stream;
-    if (n == 0 || n > ctx->gens_cap) { g_err = "fold tables: more bases than installed generators"; return BP_E_GENS_LENGTH; }
-    if (!ctx->d_G.owned) { g_err = "fold tables: build them on the ctx that owns the generator tables, then bp_gens_share"; return BP_E_ARG; }
-    ctx->ftab_G.release(); ctx->ftab_H.release(); ctx->ftab_n = 0;
+    if (n == 0 || stride == 0 || (size_t)first + (n - 1) * (size_t)stride >= ctx->gens_cap) { g_err = "fold tables: more bases than installed generators"; return BP_E_GENS_LENGTH; }
+    if (!ctx->d_G.owned && stride == 1) { g_err = "fold tables: build them on the ctx that owns the generator tables, then bp_gens_share"; return BP_E_ARG; }
+    for (DevBuf* b : {&ctx->ftab_G, &ctx->ftab_H}) { if (!b->owned) { b->p = nullptr; b->cap = 0; b->owned = true; } else b->release(); }   // (a shared view is let go, not freed)
+    ctx->ftab_n = 0; ctx->ftab_first = 0; ctx->ftab_stride = 1;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     if (!budget_bytes) budget_bytes = free_b / 4 * 3;
@@ -1455,11 +1468,16 @@ template <class C> static int ftab_build(bp_ctx* ctx, size_t n, int w, size_t bu
     const int nwin = ftab_nwin_for<C>(w);
     const size_t per_vec = (size_t)nwin * E * n * 64;
     BPCHK(ctx->ftab_G.ensure_exact(per_vec)); BPCHK(ctx->ftab_H.ensure_exact(per_vec));
-    DevBuf tmp, pref, state;
+    DevBuf tmp, pref, state, gsl;
     BPCHK(tmp.ensure_exact(E * n * 96)); BPCHK(pref.ensure_exact(E * n * 32)); BPCHK(state.ensure_exact(n * 96));
     const u32 gb = (u32)((n + 255) / 256);
+    if (stride > 1 || first) BPCHK(gsl.ensure_exact(n * 64));
     for (int v = 0; v < 2; v++) {
         const u32* gens = v ? ctx->d_H.as<u32>() : ctx->d_G.as<u32>();
+        if (gsl.p) {   // the slice as a compact vector: the builder below then runs unchanged
+            hipLaunchKernelGGL(k_cyclic_gather<Blk64>, dim3(gb), dim3(256), 0, st, gens, gsl.as<u32>(), (u32)n, first, stride);
+            gens = gsl.as<u32>();
+        }
         u32* T = v ? ctx->ftab_H.as<u32>() : ctx->ftab_G.as<u32>();
         for (int j = 0; j < nwin; j++) {
             hipLaunchKernelGGL(k_ftab_window<C>, dim3(gb), dim3(256), 0, st, gens, state.as<u32>(), tmp.as<u32>(), (u32)n, (u32)E, j == 0 ? 1 : 0);
@@ -1468,8 +1486,8 @@ template <class C> static int ftab_build(bp_ctx* ctx, size_t n, int w, size_t bu
     }
     HIPCHK(hipGetLastError());
     HIPCHK(ctx_stream_wait(ctx));
-    tmp.release(); pref.release(); state.release();
-    ctx->ftab_n = n; ctx->ftab_w = w; ctx->ftab_nwin = nwin;
+    tmp.release(); pref.release(); state.release(); gsl.release();
+    ctx->ftab_n = n; ctx->ftab_w = w; ctx->ftab_nwin = nwin; ctx->ftab_first = first; ctx->ftab_stride = stride;
     return BP_OK;
 }
 // Walks every entry of the fold tables and of the fixed-base MSM rows (ipa.cuh "integrity check"); counts the entries that break
@@ -1481,8 +1499,8 @@ template <class C> static int tables_check(bp_ctx* ctx, uint64_t* bad_fold, uint
     HIPCHK(hipMemsetAsync(d_bad, 0, 16, st));
     if (ctx->ftab_n) {
         const u32 n = (u32)ctx->ftab_n, E = 1u << (ctx->ftab_w - 1), gb = (n + 255) / 256;
-        hipLaunchKernelGGL(k_ftab_check<C>, dim3(gb), dim3(256), 0, st, ctx->d_G.as<u32>(), ctx->ftab_G.as<u32>(), n, E, (u32)ctx->ftab_nwin, d_bad);
-        hipLaunchKernelGGL(k_ftab_check<C>, dim3(gb), dim3(256), 0, st, ctx->d_H.as<u32>(), ctx->ftab_H.as<u32>(), n, E, (u32)ctx->ftab_nwin, d_bad);
+        hipLaunchKernelGGL(k_ftab_check<C>, dim3(gb), dim3(256), 0, st, ctx->d_G.as<u32>(), ctx->ftab_G.as<u32>(), n, E, (u32)ctx->ftab_nwin, d_bad, ctx->ftab_first, ctx->ftab_stride);
+        hipLaunchKernelGGL(k_ftab_check<C>, dim3(gb), dim3(256), 0, st, ctx->d_H.as<u32>(), ctx->ftab_H.as<u32>(), n, E, (u32)ctx->ftab_nwin, d_bad, ctx->ftab_first, ctx->ftab_stride);
     }
     if (ctx->fb_cap) {
         const u32 n = (u32)ctx->fb_cap, gb = (n + 255) / 256;
@@ -1498,12 +1516,21 @@ template <class C> static int tables_check(bp_ctx* ctx, uint64_t* bad_fold, uint
     if (bad_rows) *bad_rows = h[1];
     return BP_OK;
 }
+// Table columns of a state's local elements: element j (generator gens_first + j * gens_stride) is column c0 + j * cs of the ctx's
+// fold tables — whole tables (column = generator index) or a rank's slice of them; false when the elements do not lie on the columns
+static bool ftab_cols(const bp_ctx* ctx, const IpaState& s, u32& c0, u32& cs) {
+    const u32 ts = ctx->ftab_stride ? ctx->ftab_stride : 1u, tf = ctx->ftab_first;
+    if (!s.gens_stride || s.gens_stride % ts || s.gens_first < tf || (s.gens_first - tf) % ts) return false;
+    c0 = (s.gens_first - tf) / ts; cs = s.gens_stride / ts;
+    return true;
+}
 // the first-round uniform fold through the tables; false when they do not apply (then the ladder kernels run)
 template <class C> static int launch_tab_fold(bp_ctx* ctx, const IpaState& s, u32* d_G, u32* d_H, size_t n, const F4& tG, const F4& tH, bool& done) {
     done = false;
     static const bool off = getenv("ARKBP_FOLD_NOTAB") != nullptr;   // A/B switch
-    if (off || !ctx->ftab_n || !s.gens_stride || n < 64) return BP_OK;
-    if ((size_t)s.gens_first + (n - 1) * (size_t)s.gens_stride >= ctx->ftab_n) return BP_OK;   // left half reaches past the tabled bases
+    u32 c0 = 0, cs = 1;
+    if (off || !ctx->ftab_n || n < 64 || !ftab_cols(ctx, s, c0, cs)) return BP_OK;
+    if ((size_t)c0 + (n - 1) * (size_t)cs >= ctx->ftab_n) return BP_OK;   // left half reaches past the tabled bases
     FtabDigits dG, dH;
     if (!ftab_digits<C>(ctx, tG, dG) || !ftab_digits<C>(ctx, tH, dH)) return BP_OK;
     const u32 lanes = (u32)(2 * n);
@@ -1512,7 +1539,7 @@ template <class C> static int launch_tab_fold(bp_ctx* ctx, const IpaState& s, u3
     {
     ScopedK tk(ctx, BP_K_FOLD_TAB);
     hipLaunchKernelGGL(k_ipa_fold_tab<C>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, ctx->ftab_G.as<u32>(), ctx->ftab_H.as<u32>(), (u32)ctx->ftab_n,
-                       1u << (ctx->ftab_w - 1), d_G, d_H, (u32)n, dG, dH, 3, s.gens_first, s.gens_stride, ff.jac, s.d_G_in, s.d_H_in);
+                       1u << (ctx->ftab_w - 1), d_G, d_H, (u32)n, dG, dH, 3, c0, cs, ff.jac, s.d_G_in, s.d_H_in);
     }
     fold_finish_launch<C>(ctx, ff, d_G, d_H, n, 3, lanes);
     done = true;
@@ -1524,13 +1551,14 @@ template <class C> static int launch_tab_fold(bp_ctx* ctx, const IpaState& s, u3
 // round nor the next reaches the frozen-tail length
 template <class C> static bool fold_can_defer(bp_ctx* ctx, const IpaState& s, size_t n, const F4& tG1, const F4& tH1) {
     static const bool off = getenv("ARKBP_FOLD_NODEFER") != nullptr || getenv("ARKBP_FOLD_NOTAB") != nullptr;   // A/B switches
-    if (off || !ctx->ftab_n || !s.d_G_in || !s.d_H_in || !s.gens_stride) return false;
+    u32 c0 = 0, cs = 1;
+    if (off || !ctx->ftab_n || !s.d_G_in || !s.d_H_in || !ftab_cols(ctx, s, c0, cs)) return false;
     // either the whole vectors on one GPU, or this rank's index-cyclic slice (local element j = table base first + j * stride; its
     // MSMs are partial sums followed by the point-reduce) with one more LOCAL round to come
     const bool whole = s.gens_stride == 1 && s.gens_first == 0 && ctx->shard_world == 1 && s.msm_mode == -1;
     const bool slice = s.msm_mode == 2 && ctx->shard_world > 1 && s.first && n > s.min_len;
     if (!whole && !slice) return false;
-    if (n < 256 || (n & 1) || (size_t)s.gens_first + (n + n / 2 - 1) * (size_t)s.gens_stride >= ctx->ftab_n) return false;
+    if (n < 256 || (n & 1) || (size_t)c0 + (n + n / 2 - 1) * (size_t)cs >= ctx->ftab_n) return false;
     if (s.allow_freeze && n / 2 <= std::max<size_t>(ctx->tune_ipa_freeze_len, 2)) return false;
     if (!s.have_rho) return false;
     FtabDigits d;
@@ -1541,6 +1569,8 @@ template <class C> static int launch_tab_fold2(bp_ctx* ctx, const IpaState& s, u
     typedef host::Fld<typename C::Fr> S;
     done = false;
     FtabDigits3 dG, dH;
+    u32 c0 = 0, cs = 1;
+    if (!ftab_cols(ctx, s, c0, cs)) return BP_OK;
     if (!ftab_digits<C>(ctx, s.def_tG, dG.d[0]) || !ftab_digits<C>(ctx, t2G, dG.d[1]) || !ftab_digits<C>(ctx, S::mul(s.def_tG, t2G), dG.d[2])) return BP_OK;
     if (!ftab_digits<C>(ctx, s.def_tH, dH.d[0]) || !ftab_digits<C>(ctx, t2H, dH.d[1]) || !ftab_digits<C>(ctx, S::mul(s.def_tH, t2H), dH.d[2])) return BP_OK;
     const u32 lanes = (u32)(2 * m);
@@ -1549,7 +1579,7 @@ template <class C> static int launch_tab_fold2(bp_ctx* ctx, const IpaState& s, u
     {
         ScopedK tk(ctx, BP_K_FOLD_TAB);
         hipLaunchKernelGGL(k_ipa_fold_tab2<C>, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, ctx->ftab_G.as<u32>(), ctx->ftab_H.as<u32>(), (u32)ctx->ftab_n,
-                           1u << (ctx->ftab_w - 1), d_G, d_H, (u32)m, dG, dH, ff.jac, s.d_G_in, s.d_H_in, s.gens_first, s.gens_stride);
+                           1u << (ctx->ftab_w - 1), d_G, d_H, (u32)m, dG, dH, ff.jac, s.d_G_in, s.d_H_in, c0, cs);
     }
     fold_finish_launch<C>(ctx, ff, d_G, d_H, m, 3, lanes);
     done = true;
@@ -2070,14 +2100,6 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
 // are sums of per-rank partial MSMs (the <a_L, b_R> * Q term is linear too): the ctx's point-reduce callback.  When the global
 // length reaches the frozen-tail length the ranks all-gather what is left (a few hundred elements) and every rank finishes the
 // remaining rounds over the frozen generators, replicated.  L, R, a, b are bit-identical to the single-GPU result.
-template <class W8> __global__ void k_cyclic_gather(const u32* __restrict__ in, u32* __restrict__ out, u32 n_loc, u32 rank, u32 world) {
-    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_loc) return;
-    const W8* src = (const W8*)in + ((size_t)rank + (size_t)j * world);
-    ((W8*)out)[j] = *src;
-}
-struct Blk32 { uint4 a, b; };
-struct Blk64 { uint4 a, b, c, d; };
 template <class C>
 static int ipa_create_cyclic(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u32* d_Hf, const u32* d_Gtab, const u32* d_Htab, const u32* d_a, const u32* d_b,
                              size_t N, const ChallengeFn& challenge, uint64_t* L_out, uint64_t* R_out, uint64_t a_out[4], uint64_t b_out[4],
@@ -3057,8 +3079,18 @@ int bp_gens_direct_tables(bp_ctx* c, size_t count, size_t* bytes_out) {
 int bp_gens_fold_tables(bp_ctx* c, size_t count, int window_bits, size_t budget_bytes, int* window_bits_out, size_t* bytes_out) {
     if (!c || window_bits < 0 || window_bits == 1 || window_bits > 8) return BP_E_ARG;
     HIPCHK(hipSetDevice(c->device));
-    if (count == 0) { if (c->ftab_G.owned) { c->ftab_G.release(); c->ftab_H.release(); } c->ftab_n = 0; return BP_OK; }
+    if (count == 0) { if (c->ftab_G.owned) { c->ftab_G.release(); c->ftab_H.release(); } c->ftab_n = 0; c->ftab_first = 0; c->ftab_stride = 1; return BP_OK; }
     const int rc = c->curve == 0 ? ftab_build<Secq>(c, count, window_bits, budget_bytes) : ftab_build<Zorro>(c, count, window_bits, budget_bytes);
+    if (rc) return rc;
+    if (window_bits_out) *window_bits_out = c->ftab_w;
+    if (bytes_out) *bytes_out = 2 * (size_t)c->ftab_nwin * ((size_t)1 << (c->ftab_w - 1)) * c->ftab_n * 64;
+    return BP_OK;
+}
+int bp_gens_fold_tables_slice(bp_ctx* c, size_t count, int window_bits, size_t budget_bytes, int rank, int world, int* window_bits_out, size_t* bytes_out) {
+    if (!c || window_bits < 0 || window_bits == 1 || window_bits > 8 || world < 1 || rank < 0 || rank >= world || count == 0 || count % (size_t)world) return BP_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t cols = count / (size_t)world;
+    const int rc = c->curve == 0 ? ftab_build<Secq>(c, cols, window_bits, budget_bytes, (u32)rank, (u32)world) : ftab_build<Zorro>(c, cols, window_bits, budget_bytes, (u32)rank, (u32)world);
     if (rc) return rc;
     if (window_bits_out) *window_bits_out = c->ftab_w;
     if (bytes_out) *bytes_out = 2 * (size_t)c->ftab_nwin * ((size_t)1 << (c->ftab_w - 1)) * c->ftab_n * 64;
@@ -3422,7 +3454,7 @@ int bp_gens_share(bp_ctx* dst, bp_ctx* src) {
     dst->dt_tab.release(); dst->dt_cap = 0;
     if (src->dt_cap) { dst->dt_tab.p = src->dt_tab.p; dst->dt_tab.cap = src->dt_tab.cap; dst->dt_tab.owned = false; dst->dt_cap = src->dt_cap; }
     dst->fb_cap = src->fb_cap;
-    dst->ftab_n = src->ftab_n; dst->ftab_w = src->ftab_w; dst->ftab_nwin = src->ftab_nwin;
+    dst->ftab_n = src->ftab_n; dst->ftab_w = src->ftab_w; dst->ftab_nwin = src->ftab_nwin; dst->ftab_first = src->ftab_first; dst->ftab_stride = src->ftab_stride;
     return BP_OK;
 }
 

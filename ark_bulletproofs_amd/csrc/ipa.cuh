@@ -564,11 +564,12 @@ template <class C> __device__ __forceinline__ bool jac_equals_aff(const Jac& J, 
     return fe_eq_mod<F>(fe_wred<F>(J.Y), fe_mul<F>(A.y, fe_mul<F>(zz, J.Z)));
 }
 template <class C> __global__ void __launch_bounds__(256)
-k_ftab_check(const u32* __restrict__ gens, const u32* __restrict__ T, u32 n, u32 E, u32 nwin, unsigned long long* __restrict__ bad) {
+k_ftab_check(const u32* __restrict__ gens, const u32* __restrict__ T, u32 n, u32 E, u32 nwin, unsigned long long* __restrict__ bad,
+             u32 g_first = 0, u32 g_stride = 1 /* column i of the table stands for generator g_first + i * g_stride (a rank's slice) */) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 wrong = 0;
-    Aff first = load_aff_dev(gens + (size_t)i * 16);      // what T[j][0][i] must equal (j = 0), then only its Jacobian successor
+    Aff first = load_aff_dev(gens + ((size_t)g_first + (size_t)i * g_stride) * 16);      // what T[j][0][i] must equal (j = 0), then only its Jacobian successor
     Jac expect = jac_from_aff<C>(first);
 #pragma unroll 1
     for (u32 j = 0; j < nwin; j++) {

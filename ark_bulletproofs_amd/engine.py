@@ -827,11 +827,16 @@ Engine.debug_exp_iter = _debug_exp_iter
 Engine.debug_inner_product = _debug_inner_product
 
 
-def _gens_fold_tables(self, count, window_bits=0, budget_bytes=0):
-    """fixed-base tables of G[0..count), H[0..count) for the first fold round of the prover (bp_gens_fold_tables);
-    returns (window bits chosen, table bytes)"""
+def _gens_fold_tables(self, count, window_bits=0, budget_bytes=0, rank=0, world=1):
+    """fixed-base tables of G[0..count), H[0..count) for the first fold round(s) of the prover (bp_gens_fold_tables); with
+    world > 1 only this rank's slice of them (the generators rank + i * world: bp_gens_fold_tables_slice) — what the index-cyclic
+    inner-product argument of a sharded prover looks up.  Returns (window bits chosen, table bytes)"""
     w, nbytes = C.c_int(0), C.c_size_t(0)
-    check(lib().bp_gens_fold_tables(self.ctx, C.c_size_t(count), int(window_bits), C.c_size_t(budget_bytes), C.byref(w), C.byref(nbytes)), "bp_gens_fold_tables")
+    if world > 1:
+        check(lib().bp_gens_fold_tables_slice(self.ctx, C.c_size_t(count), int(window_bits), C.c_size_t(budget_bytes), int(rank), int(world), C.byref(w), C.byref(nbytes)),
+              "bp_gens_fold_tables_slice")
+    else:
+        check(lib().bp_gens_fold_tables(self.ctx, C.c_size_t(count), int(window_bits), C.c_size_t(budget_bytes), C.byref(w), C.byref(nbytes)), "bp_gens_fold_tables")
     return w.value, nbytes.value
 
 

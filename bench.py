@@ -542,7 +542,10 @@ def run_prove(args, rank, world, local):
         # bases [0, 3N/4): the first TWO fold rounds come straight from the tables (bases [0, N/2) would serve the first round only)
         # (the index-cyclic slices of a sharded prover defer their first fold the same way since round 4: same tables)
         tab_count = N * 3 // 4 if args.fold_tables >= 2 else N // 2
-        wbits, nbytes = engs[0].gens_fold_tables(tab_count, window_bits=args.fold_table_bits, budget_bytes=max(budget, 1 << 30))
+        # (one proof partitioned across the ranks: every rank keeps only ITS slice of the tables — the generators rank + i * world that its
+        # index-cyclic slice of the inner-product argument looks up: 1/world of the memory, so the budget buys wider windows)
+        wbits, nbytes = engs[0].gens_fold_tables(tab_count, window_bits=args.fold_table_bits, budget_bytes=max(budget, 1 << 30),
+                                                 rank=rank if window_sharded else 0, world=world if window_sharded else 1)
         tab_info = {"window_bits": wbits, "GB": nbytes / 1e9, "build_s": time.perf_counter() - t0, "bases": tab_count, "rounds_from_tables": 2 if tab_count > N // 2 else 1}
     for e in engs[1:]:
         e.share_gens_from(engs[0])

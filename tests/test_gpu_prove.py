@@ -190,8 +190,9 @@ def test_window_sharded_prover_ranks_as_threads(oracle, world):
                 assert proof == ref.proof and rc == 0 and rc_bad in (-4, -6)
 
 
-@pytest.mark.parametrize("two_rounds", [False, True])
-def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads(two_rounds):
+@pytest.mark.parametrize("tables", ["one_round", "two_rounds", "two_rounds_sliced"])
+def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads(tables):
+    two_rounds = tables != "one_round"
     """cfg5's partition at full-size kernels with the default thresholds: a 2^16-constraint proof by two ranks (threads, one Engine
     each on the same GPU): Pippenger windows of the commitment MSMs partitioned, the IPA index-cyclic (32768 elements per rank,
     gather at 1024), the verifier's mega-check window-sharded.  Both ranks must emit exactly the single-GPU proof."""
@@ -211,7 +212,7 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads(two_rounds):
     # MSM algorithm; BP_TUNE_MSM_FIXED_MIN lowered on every rank so that 2^16 reaches it): same proofs
     # two_rounds: fold tables over 3N/4 bases — every rank DEFERS the first fold of its slice and takes its second fold straight from
     # the tables, the round in between runs its L / R over the slice with split scalars (the single-GPU schedule of round 3, on slices)
-    single.gens_fold_tables(N * 3 // 4 if two_rounds else N // 2, window_bits=4)
+    _, whole_bytes = single.gens_fold_tables(N * 3 // 4 if two_rounds else N // 2, window_bits=4)
     single.gens_msm_tables(N)
     single.set_tuning(5, 4096)
     for (sc, prm), ref in zip(cases, refs):
@@ -224,6 +225,11 @@ def test_window_and_cyclic_sharded_prover_2pow16_ranks_as_threads(two_rounds):
         try:
             e = A.Engine(curve=cv)
             e.share_gens_from(single)
+            if tables == "two_rounds_sliced":
+                # 1/world of the fold tables per rank: only the generators rank + i * world — all its slice of the argument looks up
+                wb, nbytes = e.gens_fold_tables(N * 3 // 4, window_bits=4, rank=rank, world=world)
+                assert wb == 4 and nbytes * world == whole_bytes
+                assert e.gens_tables_check()[0] == 0
 
             def allgather(arr):
                 if np.asarray(arr).size > 8:
