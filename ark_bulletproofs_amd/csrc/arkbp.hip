@@ -2077,7 +2077,8 @@ static int ipa_create_dev(bp_ctx* ctx, const u32* d_Q, const u32* d_Gf, const u3
         HIPCHK(hipMemcpyAsync(ctx->ipa_cG.p, d_Gf, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->ipa_cH.p, d_Hf, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
         BPCHK(ctx->dt_a2.ensure(n * 16)); BPCHK(ctx->dt_b2.ensure(n * 16));   // (the folded vectors: at most n / 2 elements)
-        BPCHK(ctx->dt_ticket.ensure_zeroed(64, ctx->stream));
+        BPCHK(ctx->dt_ticket.ensure(64));
+        HIPCHK(hipMemsetAsync(ctx->dt_ticket.p, 0, 64, ctx->stream));   // (the last workgroup of k_dt_round leaves it at zero; an aborted launch would not)
         s.d_cG = ctx->ipa_cG.as<u32>(); s.d_cH = ctx->ipa_cH.as<u32>();
         s.d_a_alt = ctx->dt_a2.as<u32>(); s.d_b_alt = ctx->dt_b2.as<u32>();
         s.d_G_in = s.d_H_in = nullptr;
