@@ -285,3 +285,32 @@ def test_lockstep_replay_schedule_equals_live_transcript(oracle):
         pr = O.r1cs_prove(cv, O.SC_SHUFFLE, [4], bytes([78]) * 32, 64, m_cap=16)
         odd = list(inst); odd[2] = (O.SC_SHUFFLE, [4], pr.proof, pr.commitments, pr.publics)
         assert E.debug_verify_challenges(cv, odd, True) is None
+
+
+def test_direct_table_round_visits_exactly_the_bases_with_nonzero_scalars():
+    """The small-statement inner-product argument (csrc/small.cuh) never folds G and H: in the round with half length n, generator t of
+    the n0 original ones carries a scalar for L iff its position in the current vector, t mod 2n, lies in the UPPER half (G) / LOWER half
+    (H), and for R the other way round (k_ipa_frozen_scalars, src/inner_product_proof.rs:92-102, 112-122).  The table sums visit only
+    those: term j of a run with `fold_n = n` stands for element (j // n) * 2n + j % n + (n if fold_hi else 0) (DtSeg in small.cuh).
+    This is the index algebra of that mapping, for every round of a few sizes: each job enumerates its half exactly once, L and R
+    partition the generators, and the pairing a[(pos + n) mod 2n] <-> G[t] is the reference's (a_L with G_R, a_R with G_L)."""
+    for lg in range(1, 9):
+        n0 = 1 << lg
+        n = n0 // 2
+        while n >= 1:
+            def run(fold_hi):
+                return [(j // n) * 2 * n + j % n + (n if fold_hi else 0) for j in range(n0 // 2)]
+            upper, lower = run(True), run(False)
+            assert sorted(upper) == [t for t in range(n0) if t % (2 * n) >= n]
+            assert sorted(lower) == [t for t in range(n0) if t % (2 * n) < n]
+            assert len(set(upper) | set(lower)) == n0 and not (set(upper) & set(lower))
+            for t in range(n0):
+                pos = t % (2 * n)
+                partner = pos + n if pos < n else pos - n        # k_dt_round: idx
+                assert partner == (pos + n) % (2 * n)
+                # L: G at upper positions pairs with a_L[pos - n]; R: G at lower positions pairs with a_R[pos] = a[pos + n]
+                if pos >= n:
+                    assert partner == pos - n and partner < n
+                else:
+                    assert partner == pos + n and partner >= n
+            n //= 2
