@@ -169,8 +169,8 @@ int bp_gens_download(bp_ctx* ctx, uint64_t* G_xy, uint64_t* H_xy, size_t n);
  * Built on the ctx that owns the generators; bp_gens_share hands them on.  count = 0 frees them.  Results never depend on it. */
 int bp_gens_fold_tables(bp_ctx* ctx, size_t count, int window_bits, size_t budget_bytes, int* window_bits_out, size_t* bytes_out);
 /* The same for ONE RANK of a sharded prover (bp_ctx_set_shard, index-cyclic inner-product argument): only the generators
- * rank + i * world, i < count / world — 1/world of the memory (count = 3N/4 of a 2^22 proof on 8 GPUs at w = 8: 41 GB per rank instead of
- * 330), which is all that rank's slice ever looks up.  These tables belong to the ctx that builds them, whoever owns the generators
+ * rank + i * world, i < count / world — 1/world of the memory (count = 3N/4 of a 2^22 proof on 8 GPUs at w = 8: 110 GB per rank instead of
+ * 876), which is all that rank's slice ever looks up.  These tables belong to the ctx that builds them, whoever owns the generators
  * (bp_gens_share first, then this); bp_gens_tables_check and bp_gens_fold_tables(.., 0, ..) treat them like the whole ones.
  * count must be a multiple of world.  Results never depend on it. */
 int bp_gens_fold_tables_slice(bp_ctx* ctx, size_t count, int window_bits, size_t budget_bytes, int rank, int world, int* window_bits_out, size_t* bytes_out);
